@@ -1,0 +1,225 @@
+/*
+ * ptcore.h -- C ABI of the MI355X-native path-tracing core (libptcore.so).
+ *
+ * The library replaces ONE path of Kliaxe/PathTracer: "upload scene buffers ->
+ * dispatch the path-tracing compute shader -> accumulate into three RGBA32F
+ * images".  The reference has no plugin/FFI layer; the seam is the set of plain
+ * OpenGL calls its two host classes make.  Every entry point below names the
+ * reference call(s) it stands in for (paths relative to the reference root).
+ *
+ * Conventions
+ *   - Plain C: opaque context, pointers and sizes only.  No exceptions cross the
+ *     boundary.  Every function returning int returns PT_OK (0) or a negative
+ *     PT_ERR_* code; pt_last_error() gives a thread-local message for the last
+ *     failure on the calling thread.
+ *   - Inputs are borrowed for the duration of the call and copied (glBufferData
+ *     semantics); the context owns all device memory it allocates.
+ *   - One context = one HIP device + one stream.  Calls on a context must be
+ *     serialised by the caller; different contexts may be driven from different
+ *     threads (the reference is single-threaded: Application.cpp:51-64).
+ *   - Matrices are column-major float[16] (glm / GLSL layout).
+ *   - Image texel (x, y) lives at float offset (y * width + x) * 4; row 0 is the
+ *     GL image origin (bottom row when displayed).
+ */
+#ifndef PTCORE_H
+#define PTCORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_OK 0
+#define PT_ERR_INVALID (-1) /* bad argument (null pointer, size, enum)               */
+#define PT_ERR_STATE (-2)   /* call order: scene/params/environment missing          */
+#define PT_ERR_DEVICE (-3)  /* HIP runtime failure (message carries hipGetErrorName) */
+#define PT_ERR_NOMEM (-4)   /* host or device allocation failed                      */
+#define PT_ERR_SCENE (-5)   /* malformed BVH / primitive / material table            */
+
+#define PT_IMAGE_RADIANCE 0 /* image unit 0: radianceImage        (pathtracing.comp:8)  */
+#define PT_IMAGE_ALBEDO 1   /* image unit 1: primaryAlbedoImage   (pathtracing.comp:9)  */
+#define PT_IMAGE_NORMAL 2   /* image unit 2: primaryNormalImage   (pathtracing.comp:10) */
+
+#define PT_ACCUM_RUNNING_MEAN 0 /* mix(prev, x, 1/FrameCount): pathtracing.comp:248-265 */
+#define PT_ACCUM_SUM 1          /* prev + x: for sample-sharded multi-GPU renders       */
+
+/* Record sizes of the reference's buffers. */
+#define PT_SIZEOF_NODE 40       /* BVH::BvhNode            (BVH.h:8-21)   */
+#define PT_SIZEOF_PRIMITIVE 100 /* BVH::BvhPrimitive       (BVH.h:23-38)  */
+#define PT_SIZEOF_NODE_ALIGN 48 /* BVH::BvhNodeAlign       (BVH.h:40-48)  */
+#define PT_SIZEOF_PRIMITIVE_ALIGN 112 /* BVH::BvhPrimitiveAlign (BVH.h:50-62) */
+#define PT_SIZEOF_MATERIAL_ALIGN 176  /* MaterialAlign (PathTracingRenderer.h:163-193) */
+#define PT_SIZEOF_VERTEX 32     /* VertexSave {pos, nor, uv} (PathTracingRenderer.h:117-122) */
+
+typedef struct pt_ctx pt_ctx;
+
+/*
+ * The uniform block of the compute shader (Shaders/Library/resources.glsl:6-31) as
+ * set each frame by PathTracingApplication::UpdateMaterial
+ * (PathTracingApplication.cpp:244-274), plus two knobs the reference hard-codes.
+ */
+typedef struct pt_params {
+    float view_matrix[16];     /* ViewMatrix                                        */
+    float proj_matrix[16];     /* ProjMatrix (uploaded by the reference, unused)    */
+    float inv_proj_matrix[16]; /* InvProjMatrix = inverse(ProjMatrix), host-side    */
+    uint32_t frame_count;      /* FrameCount: ignored; pt_dispatch supplies it      */
+    float frame_dimensions[2]; /* FrameDimensions: must equal the context size or 0 */
+    uint32_t anti_aliasing_enabled;
+    float focal_length;
+    float aperture_size;
+    float aperture_shape[2];
+    float specular_modifier;
+    float specular_tint_modifier;
+    float metallic_modifier;
+    float roughness_modifier;
+    float subsurface_modifier;
+    float anisotropy_modifier;
+    float sheen_roughness_modifier;
+    float sheen_tint_modifier;
+    float clearcoat_modifier;
+    float clearcoat_roughness_modifier;
+    float refraction_modifier;
+    float transmission_modifier;
+    float debug_value_a;
+    float debug_value_b;
+    /* not uniforms in the reference: */
+    uint32_t max_bounces;     /* `const uint MaxBounceCount = 3` (pathtracing.comp:24); 0 -> 3 */
+    uint32_t accumulate_mode; /* PT_ACCUM_*                                                   */
+} pt_params;
+
+/* Counters of the most recent pt_dispatch_counted() (all zero after pt_dispatch()). */
+typedef struct pt_stats {
+    uint64_t samples;         /* (pixel, FrameCount) pairs traced                        */
+    uint64_t rays_closest;    /* closest-hit BVH queries                                 */
+    uint64_t rays_any;        /* any-hit (shadow) BVH queries                            */
+    uint64_t node_visits;     /* two-child node records fetched (child-AABB pair tests)  */
+    uint64_t triangle_tests;  /* ray/triangle tests                                      */
+    uint64_t closest_hits;    /* closest-hit queries that hit                            */
+    uint32_t max_stack_depth; /* largest traversal-stack occupancy seen                  */
+    uint32_t reserved;
+} pt_stats;
+
+/* ---------------------------------------------------------------- life cycle */
+
+/* Replaces: GL context + PathTracingRenderPass::InitializeTextures
+ * (PathTracingRenderPass.cpp:171-204: three RGBA32F width x height images) and
+ * PathTracingRenderer::InitializeBuffers (PathTracingRenderer.cpp:89-95).
+ * Fails with PT_ERR_DEVICE when no HIP device is usable: there is no CPU path. */
+int pt_create(int device, int width, int height, pt_ctx** out);
+void pt_destroy(pt_ctx* ctx);
+const char* pt_last_error(void);
+
+/* Run the context's work on a caller-owned hipStream_t (NULL = the context's own stream). */
+int pt_set_stream(pt_ctx* ctx, void* hip_stream);
+
+/* Render into caller-owned device memory (each width*height*4 floats) instead of the
+ * context's own images; pass NULLs to return to the internal images.  Stands in for
+ * glBindImageTexture units 0-2 (PathTracingRenderPass.cpp:62-64), where the images are
+ * owned by the render pass, not the shader. */
+int pt_bind_images(pt_ctx* ctx, void* d_radiance, void* d_albedo, void* d_normal);
+
+/* ------------------------------------------------- scene buffers (SSBO 0..3) */
+
+/* SSBO binding 2 (PathTracingRenderer.cpp:566-613): `count` BvhNodeAlign records of 48 B,
+ * node 0 the dummy, root = node 1. */
+int pt_upload_nodes(pt_ctx* ctx, const void* nodes48, size_t count);
+/* SSBO binding 3 (PathTracingRenderer.cpp:615-662): BvhPrimitiveAlign records of 112 B in
+ * post-build order. */
+int pt_upload_primitives(pt_ctx* ctx, const void* prims112, size_t count);
+/* SSBO binding 1 (PathTracingRenderer.cpp:509-564): MaterialAlign records of 176 B.  The 11
+ * 64-bit bindless handles are reinterpreted as 1-based slots of pt_upload_texture
+ * (0 = no texture, as in the reference). */
+int pt_upload_materials(pt_ctx* ctx, const void* mats176, size_t count);
+/* Stands in for a resident bindless sampler2D (Texture2DLoader.cpp:16-62;
+ * PathTracingRenderPass.cpp:47-50).  slot >= 1.  channels 1..4; texels are u8 (unorm,
+ * is_srgb decodes the colour channels like GL_SRGB8) or f32 when is_float.  Row 0 is the
+ * GL row 0 (the caller applies the loader's vertical flip).  Sampling is bilinear, REPEAT,
+ * base level. */
+int pt_upload_texture(pt_ctx* ctx, int slot, int width, int height, int channels, int is_srgb, int is_float,
+                      const void* texels);
+/* SSBO binding 0 + the two environment textures (PathTracingRenderer.cpp:463-507): RGB32F
+ * HDRI of w x h (row 0 first, not flipped).  Builds the importance-sampling cache on the
+ * host (CalculateHdriCache, PathTracingRenderer.cpp:776-919). */
+int pt_upload_environment(pt_ctx* ctx, const float* hdri_rgb, int width, int height);
+/* Same, with a caller-computed cache (w*h*3 floats: sample x, sample y, pdf). */
+int pt_upload_environment_with_cache(pt_ctx* ctx, const float* hdri_rgb, const float* cache_rgb, int width,
+                                     int height);
+
+/* ------------------------- host-side scene processing (the reference's L4 CPU code) */
+
+/* PathTracingRenderer::AddPathTracingModel / ClearPathTracingModels / ProcessBuffers
+ * (PathTracingRenderer.cpp:156-168,170-461): queue sub-meshes (32-B vertices, indices of
+ * index_bytes = 1, 2 or 4 each, one 176-B material per sub-mesh), then flatten to a triangle
+ * soup in submission order, build the sweep-SAH BVH (leaf size 4), convert to the aligned
+ * layouts and upload nodes, primitives and materials.  The environment is uploaded
+ * separately.  World matrices are not applied (the reference stores but never uses them). */
+int pt_add_model(pt_ctx* ctx, const void* vertices32, size_t vertex_count, const void* indices,
+                 size_t index_count, int index_bytes, const void* material176);
+int pt_clear_models(pt_ctx* ctx);
+int pt_process_buffers(pt_ctx* ctx);
+
+/* BVH::BuildBvhWithSah (BVH.cpp:91-238) as called at PathTracingRenderer.cpp:575-584:
+ * prims100 (count records of 100 B) is reordered in place; nodes40_out receives the nodes
+ * including the zeroed dummy node 0.  Bit-identical to the reference built with libstdc++.
+ * *node_count_out = number of nodes written.  PT_ERR_INVALID if node_capacity is too small
+ * (2*count+1 always suffices). */
+int pt_build_bvh_sah(void* prims100, size_t count, int leaf_size, void* nodes40_out, size_t node_capacity,
+                     size_t* node_count_out);
+/* Triangle-soup assembly for one sub-mesh (PathTracingRenderer.cpp:414-446). */
+int pt_assemble_primitives(const void* vertices32, size_t vertex_count, const void* indices, size_t index_count,
+                           int index_bytes, uint32_t mesh_index, void* prims100_out);
+/* BvhNode -> BvhNodeAlign, BvhPrimitive -> BvhPrimitiveAlign
+ * (PathTracingRenderer.cpp:590-605,623-654). */
+int pt_align_nodes(const void* nodes40, size_t count, void* nodes48_out);
+int pt_align_primitives(const void* prims100, size_t count, void* prims112_out);
+/* CalculateHdriCache (PathTracingRenderer.cpp:803-901): cache_out = w*h*3 floats. */
+int pt_calculate_hdri_cache(const float* hdri_rgb, int width, int height, float* cache_out);
+/* glm::lookAt / glm::perspective (right-handed, -1..1 depth) / glm::inverse, as used by
+ * Runtime/Camera/Camera.cpp:10-18 and PathTracingApplication.cpp:233-235,250. */
+void pt_look_at(const float eye[3], const float center[3], const float up[3], float out16[16]);
+void pt_perspective(float fovy, float aspect, float z_near, float z_far, float out16[16]);
+void pt_inverse4(const float in16[16], float out16[16]);
+/* Fills every field with the reference's defaults (PathTracingApplication.h:108-144,
+ * PathTracingApplication.cpp:229-242) for a width x height frame. */
+void pt_default_params(int width, int height, pt_params* out);
+
+/* ------------------------------------------------------------------ per frame */
+
+/* PathTracingApplication::UpdateMaterial (PathTracingApplication.cpp:244-274) +
+ * Material::Use() uniform flush (PathTracingRenderPass.cpp:59). */
+int pt_set_params(pt_ctx* ctx, const pt_params* params);
+/* Zero the three images (the reference relies on weight 1 at FrameCount 1 instead:
+ * pathtracing.comp:248; Texture2DObject.cpp:19-22). */
+int pt_clear(pt_ctx* ctx);
+/* glDispatchCompute + glMemoryBarrier (PathTracingRenderPass.cpp:66-72), for FrameCount =
+ * frame_first, frame_first + frame_stride, ... (frame_count values) in one launch; every
+ * pixel of the frame is rendered (the reference drops the last height % 16 rows).
+ * Asynchronous on the context's stream. */
+int pt_dispatch(pt_ctx* ctx, uint32_t frame_first, uint32_t frame_count, uint32_t frame_stride);
+/* Same image result, and additionally fills the pt_stats counters (slower). */
+int pt_dispatch_counted(pt_ctx* ctx, uint32_t frame_first, uint32_t frame_count, uint32_t frame_stride);
+/* Multiply the three images by `scale` (sum mode: 1/N after the cross-GPU reduce). */
+int pt_scale_images(pt_ctx* ctx, float scale);
+int pt_synchronize(pt_ctx* ctx);
+/* glGetTexImage(GL_RGBA, GL_FLOAT) (PathTracingRenderPass.cpp:89-99 reads GL_RGB): copies
+ * width*height*4 floats to host memory; synchronises the stream. */
+int pt_read_image(pt_ctx* ctx, int which, float* rgba_out);
+int pt_get_stats(pt_ctx* ctx, pt_stats* out);
+/* Milliseconds spent by the device in the most recent dispatch (HIP events on the context's
+ * stream); synchronises. */
+int pt_last_dispatch_ms(pt_ctx* ctx, float* ms_out);
+/* Device-side sizes of the packed scene, for bandwidth accounting. */
+int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, uint64_t* shading_bytes);
+
+/* Test hook, not part of the drop-in surface (no counterpart in the reference): evaluates one
+ * float32 building block of the kernels element-wise on the device so that tests can compare it
+ * bit for bit with a CPU evaluation of the same operation sequence.  fn: 0 sin, 1 cos, 2 asin,
+ * 3 atan2(a,b), 4 pow(a,b), 5 min, 6 max, 7 a/b, 8 sqrt, 9 1/sqrt.  a, b, out: host arrays of n. */
+int pt_debug_eval_math(int device, int fn, const float* a, const float* b, float* out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTCORE_H */

@@ -1,0 +1,42 @@
+// Host-side (CPU) scene processing of the path: declarations.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "layouts.h"
+
+namespace ptcore {
+
+// host_bvh.cpp
+size_t BuildBvhWithSah(RefPrimitive* prims, size_t count, int leafSize, std::vector<RefNode>& nodes,
+                       int threads = 0);
+void AssemblePrimitives(const RefVertex* v, const void* indices, size_t indexCount, int indexBytes,
+                        uint32_t meshIndex, RefPrimitive* out);
+void AlignNodes(const RefNode* in, size_t count, RefNodeAlign* out);
+void AlignPrimitives(const RefPrimitive* in, size_t count, RefPrimitiveAlign* out);
+
+// host_env.cpp
+void CalculateHdriCache(const float* rgb, int width, int height, float* cacheOut);
+
+// host_camera.cpp
+void LookAt(const float eye[3], const float center[3], const float up[3], float out[16]);
+void Perspective(float fovy, float aspect, float zNear, float zFar, float out[16]);
+void Inverse4(const float in[16], float out[16]);
+
+// host_pack.cpp: reference layouts -> packed device layouts, with validation.
+struct PackedScene {
+    std::vector<DevNode> nodes;
+    std::vector<DevTriangle> triangles;
+    std::vector<DevShading> shading;
+    int32_t rootRef = 0;
+    int maxDepth = 0;  // interior levels below (and including) the root; bounds the traversal stack
+};
+// Returns empty string on success, else a description of what is malformed.
+std::string PackScene(const RefNodeAlign* nodes, size_t nodeCount, const RefPrimitiveAlign* prims,
+                      size_t primCount, size_t materialCount, PackedScene& out);
+std::string PackMaterials(const RefMaterialAlign* mats, size_t count, size_t textureSlots,
+                          const std::vector<int>& slotToTexture, std::vector<DevMaterial>& out);
+
+}  // namespace ptcore

@@ -1,0 +1,408 @@
+// HIP kernels of the path-tracing core for gfx950 (wave64).
+//
+// Execution model
+//   * One lane owns one pixel for the whole launch and walks that pixel's FrameCount values
+//     (samples) in order.  A wave covers an 8x8 pixel tile, a 256-thread block a 16x16 tile.
+//   * Lanes regenerate: a lane whose path ends accumulates its sample into the images and
+//     immediately starts its next FrameCount, so waves stay full while paths of different
+//     length (Russian roulette, misses, up to max_bounces) run side by side.  A wave leaves
+//     when every lane has finished every sample -- an exit condition every lane reaches.
+//   * BVH traversal keeps the per-lane stack of postponed far children in LDS
+//     (entry k of thread t at word k*256 + t: consecutive lanes hit consecutive banks), the
+//     near child is followed directly without touching the stack.
+//   * The block -> tile map hands each of the 8 XCDs a contiguous band of tiles, so the BVH
+//     sub-trees an XCD's L2 holds are the ones its blocks keep asking for.
+//
+// Same results as the reference shader's traversal (intersection.glsl:115-199,230-315):
+// children are visited near-first with the shader's tie rule, leaves are scanned in order
+// with a strict `<`, so the same triangle wins.  Two things differ without changing the
+// result: sub-trees whose box entry distance lies beyond the best hit so far are skipped
+// (the shader never prunes), and the stack never overflows (the shader's 16-entry stack
+// aborts traversal when it does).
+#pragma once
+#include "shading.h"
+
+namespace ptcore {
+
+constexpr int kBlockThreads = 256;
+// Entry distance must exceed the best hit by this factor before a sub-tree is skipped: box and
+// triangle distances are rounded independently, the margin keeps a triangle whose computed
+// distance ties or narrowly beats the current best from being culled with its box.
+constexpr float kPruneMargin = 1.0009765625f;  // 1 + 2^-10
+
+struct TraceCounters {
+    unsigned nodeVisits, triangleTests, maxStack;
+};
+
+struct Hit {
+    float t, u, v;
+    int prim;
+};
+
+// Slab test with the shader's return convention (intersection.glsl:63-77): entry distance, or
+// exit distance when the origin is inside, or -1 on a miss.  t0 is also returned for pruning.
+PT_DEV float hitAabb(v3 o, v3 inv, float minx, float miny, float minz, float maxx, float maxy, float maxz, float& t0out)
+{
+    float fx = (maxx - o.x) * inv.x, fy = (maxy - o.y) * inv.y, fz = (maxz - o.z) * inv.z;
+    float nx = (minx - o.x) * inv.x, ny = (miny - o.y) * inv.y, nz = (minz - o.z) * inv.z;
+    float t1 = fmin_(fmax_(fx, nx), fmin_(fmax_(fy, ny), fmax_(fz, nz)));
+    float t0 = fmax_(fmin_(fx, nx), fmax_(fmin_(fy, ny), fmin_(fz, nz)));
+    t0out = t0;
+    return (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
+}
+
+// ANY = false: closest hit (returns true and fills `hit` when something was hit).
+// ANY = true : occlusion query, returns on the first triangle hit.
+template <bool ANY, bool COUNT>
+PT_DEV bool traverse(const DevScene& S, int rootRef, v3 o, v3 d, int* stack, Hit& hit, TraceCounters& tc)
+{
+    const v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float bestT = kFltMax;
+    int bestPrim = -1;
+    float bestU = 0.0f, bestV = 0.0f;
+    int sp = 0;
+    int cur = rootRef;
+    for (;;) {
+        if (cur >= 0) {
+            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
+            const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+            if (COUNT) tc.nodeVisits++;
+            float t0l, t0r;
+            const float dl = hitAabb(o, inv, a.x, a.y, a.z, b.x, b.y, b.z, t0l);
+            const float dr = hitAabb(o, inv, c.x, c.y, c.z, e.x, e.y, e.z, t0r);
+            bool hl = dl > 0.0f, hr = dr > 0.0f;
+            if (!ANY) {
+                const float limit = bestT * kPruneMargin;
+                hl = hl && !(t0l > limit);
+                hr = hr && !(t0r > limit);
+            }
+            const int left = __float_as_int(a.w), right = __float_as_int(b.w);
+            if (hl && hr) {
+                const bool leftFirst = dl < dr;  // intersection.glsl:169-180
+                stack[sp * kBlockThreads] = leftFirst ? right : left;
+                sp++;
+                if (COUNT) tc.maxStack = sp > (int)tc.maxStack ? (unsigned)sp : tc.maxStack;
+                cur = leftFirst ? left : right;
+                continue;
+            }
+            if (hl) {
+                cur = left;
+                continue;
+            }
+            if (hr) {
+                cur = right;
+                continue;
+            }
+        } else {
+            const unsigned bits = ~(unsigned)cur;
+            const unsigned first = bits >> 3, count = (bits & 7u) + 1u;
+            bool found = false;
+            for (unsigned i = 0; i < count; i++) {
+                const float4* tp = reinterpret_cast<const float4*>(S.triangles + first + i);
+                const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                if (COUNT) tc.triangleTests++;
+                // Moller-Trumbore with the shader's expressions (intersection.glsl:26-40); the edges
+                // and their cross product come precomputed from the host.
+                const v3 n = mk3(q0.w, q1.w, q2.w);
+                const v3 ab = mk3(q1.x, q1.y, q1.z), ac = mk3(q2.x, q2.y, q2.z);
+                const v3 ao = o - mk3(q0.x, q0.y, q0.z);
+                const v3 dao = cross(ao, d);
+                const float det = -dot(d, n);
+                const float invDet = 1.0f / det;
+                const float dst = dot(ao, n) * invDet;
+                const float u = dot(ac, dao) * invDet;
+                const float v = -dot(ab, dao) * invDet;
+                const float w = 1.0f - u - v;
+                const bool ok = det >= 1e-10f && dst >= 0.0f && u >= 0.0f && v >= 0.0f && w >= 0.0f;
+                if (ANY) {
+                    if (ok) {
+                        found = true;
+                        break;
+                    }
+                } else if (ok && dst < bestT) {
+                    bestT = dst;
+                    bestU = u;
+                    bestV = v;
+                    bestPrim = (int)(first + i);
+                }
+            }
+            if (ANY && found) return true;
+        }
+        if (sp == 0) break;
+        sp--;
+        cur = stack[sp * kBlockThreads];
+    }
+    if (ANY) return false;
+    hit.t = bestT;
+    hit.u = bestU;
+    hit.v = bestV;
+    hit.prim = bestPrim;
+    return bestPrim >= 0;
+}
+
+// Primary ray: pathtracing.comp:150-200 (inverse(ViewMatrix) arrives precomputed in P.invView).
+PT_DEV void mulMat4(const float* M, float x, float y, float z, float w, float out[4])
+{
+    for (int i = 0; i < 4; i++) out[i] = ((M[0 + i] * x + M[4 + i] * y) + M[8 + i] * z) + M[12 + i] * w;
+}
+PT_DEV void primaryRay(const DevParams& P, float u, float v, unsigned& rng, v3& ro, v3& rd)
+{
+    float vp[4];
+    mulMat4(P.invProj, u * 2.0f - 1.0f, v * 2.0f - 1.0f, 0.0f, 1.0f, vp);
+    v3 origin = mk3(vp[0], vp[1], vp[2]) / vp[3];
+    v3 direction = normalize3(origin);
+    float o4[4], d4[4];
+    mulMat4(P.invView, origin.x, origin.y, origin.z, 1.0f, o4);
+    mulMat4(P.invView, direction.x, direction.y, direction.z, 0.0f, d4);
+    ro = mk3(o4[0], o4[1], o4[2]);
+    rd = mk3(d4[0], d4[1], d4[2]);
+    if (P.apertureSize != 0.0f) {  // thin lens (:166-187)
+        const float* VM = P.view;
+        v3 cameraForward = -mk3(VM[8], VM[9], VM[10]);
+        v3 cameraUp = mk3(VM[4], VM[5], VM[6]);
+        v3 cameraRight = cross(cameraUp, cameraForward);
+        v3 focalPoint = ro + rd * P.focalLength;
+        float r1 = randomValue(rng);
+        float r2 = randomValue(rng);
+        v3 h = hemispherePointCos(r1, r2);
+        float ax = h.x * P.apertureShapeX * P.apertureSize;
+        float ay = h.y * P.apertureShapeY * P.apertureSize;
+        ro = ro + cameraRight * ax + cameraUp * ay;
+        rd = normalize3(focalPoint - ro);
+    }
+}
+
+// blockIdx -> tile index such that blocks sharing an XCD (blockIdx % 8) cover one contiguous
+// band of tiles.  Bijective for any tile count.
+PT_DEV unsigned xcdRemap(unsigned b, unsigned total)
+{
+    const unsigned q = total / 8u, r = total % 8u;
+    const unsigned xcd = b % 8u, local = b / 8u;
+    const unsigned base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return base + local;
+}
+
+PT_DEV float4 accumulate(float4 prev, v3 x, float weight, unsigned mode)
+{
+    if (mode == 0u)  // mix(prev, vec4(x, 1), weight): pathtracing.comp:248-260
+        return make_float4(mix_(prev.x, x.x, weight), mix_(prev.y, x.y, weight), mix_(prev.z, x.z, weight),
+                           mix_(prev.w, 1.0f, weight));
+    return make_float4(prev.x + x.x, prev.y + x.y, prev.z + x.z, prev.w + 1.0f);
+}
+
+template <int STACK, bool COUNT>
+__global__ __launch_bounds__(kBlockThreads) void renderKernel(DevParams P, DevScene S, float4* __restrict__ radianceImg,
+                                                             float4* __restrict__ albedoImg,
+                                                             float4* __restrict__ normalImg, DevCounters* counters)
+{
+    __shared__ int s_stack[STACK * kBlockThreads];
+    const unsigned tid = threadIdx.x;
+    int* stack = s_stack + tid;
+
+    const unsigned tile = xcdRemap(blockIdx.x, P.tilesX * P.tilesY);
+    const unsigned tileX = tile % P.tilesX, tileY = tile / P.tilesX;
+    const unsigned wave = tid >> 6, lane = tid & 63u;
+    const unsigned px = tileX * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const unsigned py = tileY * 16u + (wave >> 1) * 8u + (lane >> 3);
+    const bool inside = px < P.width && py < P.height;
+    const unsigned pixelIndex = py * (unsigned)P.frameW + px;  // uint(FrameDimensions.x), pathtracing.comp:213
+    const size_t texel = (size_t)py * P.width + px;
+
+    unsigned nRays = 0, nShadow = 0, nHits = 0, nSamples = 0;
+    TraceCounters tc{0u, 0u, 0u};
+
+    // per-path state
+    unsigned k = 0;  // index of the next FrameCount value of this pixel
+    const unsigned kEnd = inside ? P.frameCount : 0u;
+    bool active = false;
+    unsigned rng = 0, bounce = 0, frame = 0;
+    v3 ro = splat(0.0f), rd = splat(0.0f);
+    v3 radiance = splat(0.0f), throughput = splat(1.0f), f = splat(1.0f);
+    v3 albedoRes = splat(0.0f), normalRes = splat(0.0f);
+    float pdfBsdf = 1.0f;
+
+    for (;;) {
+        if (!active && k < kEnd) {
+            // main(): pathtracing.comp:206-245
+            frame = P.frameFirst + k * P.frameStride;
+            rng = pixelIndex + frame * 719393u;
+            float u = ((float)px + 0.5f) / P.frameW, v = ((float)py + 0.5f) / P.frameH;
+            if (P.antiAliasing != 0u) {
+                float r1 = randomValue(rng);
+                float r2 = randomValue(rng);
+                u = u + (r1 - 0.5f) / P.frameW;
+                v = v + (r2 - 0.5f) / P.frameH;
+            }
+            primaryRay(P, u, v, rng, ro, rd);
+            radiance = splat(0.0f);
+            throughput = splat(1.0f);
+            f = splat(1.0f);
+            pdfBsdf = 1.0f;
+            albedoRes = splat(0.0f);
+            normalRes = splat(0.0f);
+            bounce = 0;
+            active = true;
+            nSamples++;
+        }
+        if (!__any(active)) break;
+        if (active) {
+            // one iteration of PathTrace's bounce loop (pathtracing.comp:25-140)
+            bool done = false;
+            Hit hit;
+            nRays++;
+            const bool didHit = traverse<false, COUNT>(S, P.rootRef, ro, rd, stack, hit, tc);
+            if (!didHit) {
+                float pdfLight = 0.0f;
+                v3 colorLight = evaluateHdri(S, P.envW, P.envH, P.hdriW, P.hdriH, rd, pdfLight);
+                float misWeight = 1.0f;
+                if (bounce > 0u) {
+                    float t = pdfBsdf * pdfBsdf;
+                    misWeight = t / (pdfLight * pdfLight + t);
+                }
+                if (misWeight > 0.0f) radiance = radiance + misWeight * throughput * colorLight * f / pdfBsdf;
+                done = true;
+            } else {
+                nHits++;
+                // hit attributes of the winning triangle (intersection.glsl:41-57)
+                const float w = 1.0f - hit.u - hit.v;
+                const v3 P0 = ro + rd * hit.t;
+                const float4* sp = reinterpret_cast<const float4*>(S.shading + hit.prim);
+                const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
+                const float uvx = s0.w * w + s2.w * hit.u + s3.y * hit.v;
+                const float uvy = s1.w * w + s3.x * hit.u + s3.z * hit.v;
+                v3 N = normalize3(mk3(s0.x, s0.y, s0.z) * w + mk3(s1.x, s1.y, s1.z) * hit.u + mk3(s2.x, s2.y, s2.z) * hit.v);
+                const v3 Ng = mk3(s4.x, s4.y, s4.z);
+                const unsigned meshIndex = __float_as_uint(s3.w);
+                v3 tangent = splat(0.0f);
+                if (S.materials[meshIndex].tex[kTexNormal] >= 0) {
+                    const float4* tp = reinterpret_cast<const float4*>(S.triangles + hit.prim);
+                    const float4 q1 = tp[1], q2 = tp[2];
+                    const float dBx = s2.w - s0.w, dBy = s3.x - s1.w, dCx = s3.y - s0.w, dCy = s3.z - s1.w;
+                    const float invTd = 1.0f / (dBx * dCy - dBy * dCx);
+                    tangent = (mk3(q1.x, q1.y, q1.z) * dCy - mk3(q2.x, q2.y, q2.z) * dBy) * invTd;
+                }
+                const MaterialEval me = evaluateMaterial(S, P, meshIndex, uvx, uvy, N, tangent);
+                const v3 V = -rd;
+                const Surface surf = makeSurface(me, N, V);
+                radiance = radiance + throughput * surf.emission;
+
+                // next-event estimation towards the HDRI (pathtracing.comp:64-102)
+                const v3 shadowOrigin = offsetRay(P0, Ng);
+                const v3 Ll = sampleHdri(S, P.envW, P.envH, rng);
+                if (dot(N, Ll) > 0.0f) {
+                    nShadow++;
+                    Hit dummy;
+                    const bool occluded = traverse<true, COUNT>(S, P.rootRef, shadowOrigin, Ll, stack, dummy, tc);
+                    if (!occluded) {
+                        float pdfLight = 0.0f;
+                        v3 colorLight = evaluateHdri(S, P.envW, P.envH, P.hdriW, P.hdriH, Ll, pdfLight);
+                        const Dir dl = makeDir(surf, Ll);
+                        pdfBsdf = 0.0f;
+                        f = evaluateBsdf(surf, dl, pdfBsdf);
+                        if (pdfBsdf > 0.0f) {
+                            float t = pdfLight * pdfLight;
+                            float misWeight = t / (pdfBsdf * pdfBsdf + t);
+                            if (misWeight > 0.0f) radiance = radiance + misWeight * throughput * colorLight * f / pdfLight;
+                        }
+                    }
+                }
+
+                // BSDF sampling, Russian roulette, next ray (pathtracing.comp:104-139)
+                const v3 L = sampleBsdf(surf, rng);
+                const Dir ds = makeDir(surf, L);
+                pdfBsdf = 0.0f;
+                f = evaluateBsdf(surf, ds, pdfBsdf);
+                if (pdfBsdf <= 0.0f) {
+                    done = true;
+                } else {
+                    const float p = fmax_(throughput.x, fmax_(throughput.y, throughput.z));
+                    if (randomValue(rng) >= p) {
+                        done = true;
+                    } else {
+                        throughput = throughput * (1.0f / p);
+                        throughput = throughput * (f / pdfBsdf);
+                        ro = shadowOrigin;  // OffsetRay(hitPosition, geometryNormal) again (:131)
+                        rd = L;
+                        if (bounce == 0u) {
+                            albedoRes = surf.albedo;
+                            normalRes = N;
+                        }
+                        bounce++;
+                        if (bounce >= P.maxBounces) done = true;
+                    }
+                }
+            }
+            if (done) {
+                const float weight = 1.0f / (float)frame;
+                radianceImg[texel] = accumulate(radianceImg[texel], radiance, weight, P.accumulateMode);
+                albedoImg[texel] = accumulate(albedoImg[texel], albedoRes, weight, P.accumulateMode);
+                normalImg[texel] = accumulate(normalImg[texel], normalRes, weight, P.accumulateMode);
+                active = false;
+                k++;
+            }
+        }
+    }
+
+    // counters: wave-level reduction, one atomic per wave and counter
+    auto waveSum = [](unsigned v) {
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        return v;
+    };
+    const unsigned sRays = waveSum(nRays), sShadow = waveSum(nShadow), sHits = waveSum(nHits), sSamples = waveSum(nSamples);
+    if (lane == 0) {
+        atomicAdd(&counters->raysClosest, (unsigned long long)sRays);
+        atomicAdd(&counters->raysAny, (unsigned long long)sShadow);
+        atomicAdd(&counters->closestHits, (unsigned long long)sHits);
+        atomicAdd(&counters->samples, (unsigned long long)sSamples);
+    }
+    if (COUNT) {
+        const unsigned sNodes = waveSum(tc.nodeVisits), sTris = waveSum(tc.triangleTests);
+        unsigned m = tc.maxStack;
+        for (int off = 32; off > 0; off >>= 1) {
+            unsigned o = __shfl_down(m, off, 64);
+            m = o > m ? o : m;
+        }
+        if (lane == 0) {
+            atomicAdd(&counters->nodeVisits, (unsigned long long)sNodes);
+            atomicAdd(&counters->triangleTests, (unsigned long long)sTris);
+            atomicMax(&counters->maxStack, m);
+        }
+    }
+}
+
+__global__ void scaleImagesKernel(float4* a, float4* b, float4* c, size_t n, float s)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float4 x = a[i], y = b[i], z = c[i];
+        a[i] = make_float4(x.x * s, x.y * s, x.z * s, x.w * s);
+        b[i] = make_float4(y.x * s, y.y * s, y.z * s, y.w * s);
+        c[i] = make_float4(z.x * s, z.y * s, z.z * s, z.w * s);
+    }
+}
+
+// Element-wise evaluation of the float32 building blocks, so tests can compare them bit for bit
+// with a CPU evaluation of the same operation sequences.
+__global__ void evalMathKernel(int fn, const float* a, const float* b, float* out, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i], y = b[i];
+    float r;
+    switch (fn) {
+    case 0: r = sin_(x); break;
+    case 1: r = cos_(x); break;
+    case 2: r = asin_(x); break;
+    case 3: r = atan2_(x, y); break;
+    case 4: r = pow_(x, y); break;
+    case 5: r = fmin_(x, y); break;
+    case 6: r = fmax_(x, y); break;
+    case 7: r = x / y; break;
+    case 8: r = sqrt_(x); break;
+    default: r = rsqrt_(x); break;
+    }
+    out[i] = r;
+}
+
+}  // namespace ptcore

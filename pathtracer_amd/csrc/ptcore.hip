@@ -1,0 +1,719 @@
+// libptcore.so: the C ABI declared in include/ptcore.h.
+//
+// Host-side plumbing only: argument checks, copies of the caller's reference-layout buffers,
+// repacking into the device layouts (host_pack.cpp), uploads, launches.  There is no CPU
+// rendering path in this library: without a HIP device pt_create fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ptcore.h"
+#include "host.h"
+#include "kernels.h"
+
+using namespace ptcore;
+
+namespace {
+
+thread_local std::string g_lastError;
+
+int fail(int code, const std::string& msg)
+{
+    g_lastError = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(PT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorName(e_) + " (" +        \
+                                           hipGetErrorString(e_) + ")");                               \
+    } while (0)
+
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t capacity = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= capacity && ptr) return hipSuccess;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        capacity = 0;
+        hipError_t e = hipMalloc(&ptr, bytes ? bytes : 16);
+        if (e == hipSuccess) capacity = bytes ? bytes : 16;
+        return e;
+    }
+    void release()
+    {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        capacity = 0;
+    }
+};
+
+struct HostTexture {
+    int width = 0, height = 0, channels = 0, format = 0;
+    std::vector<unsigned char> bytes;
+    bool present = false;
+};
+
+struct PendingModel {
+    std::vector<RefVertex> vertices;
+    std::vector<uint32_t> indices;
+    RefMaterialAlign material;
+};
+
+}  // namespace
+
+struct pt_ctx {
+    int device = 0;
+    int width = 0, height = 0;
+    hipStream_t ownStream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+    bool timed = false;
+
+    // caller-supplied reference-layout buffers (copied at upload, like glBufferData)
+    std::vector<RefNodeAlign> nodes;
+    std::vector<RefPrimitiveAlign> prims;
+    std::vector<RefMaterialAlign> materials;
+    std::vector<HostTexture> textures;  // index = slot
+    std::vector<float> envColorPdf;     // float4 per texel
+    std::vector<float> envSample;       // float2 per texel
+    int envW = 0, envH = 0;
+    bool geometryDirty = true, materialsDirty = true, texturesDirty = true, envDirty = true;
+    bool haveParams = false;
+    pt_params params{};
+    std::vector<PendingModel> models;
+
+    // device side
+    DeviceBuffer dNodes, dTriangles, dShading, dMaterials, dTextures, dTexels, dSrgbLut, dEnvColorPdf, dEnvSample;
+    DeviceBuffer dImages[3];
+    DeviceBuffer dCounters;
+    float4* bound[3] = {nullptr, nullptr, nullptr};
+    int32_t rootRef = 0;
+    int maxDepth = 0;
+    size_t nodeBytes = 0, triangleBytes = 0, shadingBytes = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int previous = -1;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&previous) != hipSuccess) previous = -1;
+        if (previous != device) (void)hipSetDevice(device);
+    }
+    ~DeviceGuard()
+    {
+        if (previous >= 0) (void)hipSetDevice(previous);
+    }
+};
+
+float4* imagePtr(pt_ctx* c, int which) { return c->bound[which] ? c->bound[which] : (float4*)c->dImages[which].ptr; }
+
+int syncScene(pt_ctx* c)
+{
+    if (c->nodes.empty() || c->prims.empty()) return fail(PT_ERR_STATE, "no BVH nodes / primitives uploaded");
+    if (c->materials.empty()) return fail(PT_ERR_STATE, "no materials uploaded");
+    if (c->envW == 0) return fail(PT_ERR_STATE, "no environment uploaded");
+    if (!c->haveParams) return fail(PT_ERR_STATE, "pt_set_params has not been called");
+
+    if (c->geometryDirty) {
+        PackedScene packed;
+        std::string err = PackScene(c->nodes.data(), c->nodes.size(), c->prims.data(), c->prims.size(),
+                                    c->materials.size(), packed);
+        if (!err.empty()) return fail(PT_ERR_SCENE, err);
+        if (packed.maxDepth > 64)
+            return fail(PT_ERR_SCENE, "BVH is " + std::to_string(packed.maxDepth) + " interior levels deep; the traversal stack holds 64");
+        const size_t nb = packed.nodes.size() * sizeof(DevNode), tb = packed.triangles.size() * sizeof(DevTriangle),
+                     sb = packed.shading.size() * sizeof(DevShading);
+        HIP_TRY(c->dNodes.ensure(nb));
+        HIP_TRY(c->dTriangles.ensure(tb));
+        HIP_TRY(c->dShading.ensure(sb));
+        if (nb) HIP_TRY(hipMemcpyAsync(c->dNodes.ptr, packed.nodes.data(), nb, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->dTriangles.ptr, packed.triangles.data(), tb, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->dShading.ptr, packed.shading.data(), sb, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));  // `packed` dies at the end of this scope
+        c->rootRef = packed.rootRef;
+        c->maxDepth = packed.maxDepth;
+        c->nodeBytes = nb;
+        c->triangleBytes = tb;
+        c->shadingBytes = sb;
+        c->geometryDirty = false;
+    }
+    if (c->texturesDirty) {
+        std::vector<DevTexture> table;
+        std::vector<unsigned char> arena;
+        for (const HostTexture& t : c->textures) {
+            if (!t.present) continue;
+            DevTexture d{};
+            while (arena.size() % 16) arena.push_back(0);
+            d.offset = arena.size();
+            d.width = t.width;
+            d.height = t.height;
+            d.channels = t.channels;
+            d.format = t.format;
+            arena.insert(arena.end(), t.bytes.begin(), t.bytes.end());
+            table.push_back(d);
+        }
+        float lut[256];
+        for (int i = 0; i < 256; i++) {  // GL_SRGB8 decode
+            double s = i / 255.0;
+            lut[i] = (float)(s <= 0.04045 ? s / 12.92 : std::pow((s + 0.055) / 1.055, 2.4));
+        }
+        HIP_TRY(c->dTextures.ensure(table.size() * sizeof(DevTexture)));
+        HIP_TRY(c->dTexels.ensure(arena.size()));
+        HIP_TRY(c->dSrgbLut.ensure(sizeof(lut)));
+        if (!table.empty()) {
+            HIP_TRY(hipMemcpyAsync(c->dTextures.ptr, table.data(), table.size() * sizeof(DevTexture), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->dTexels.ptr, arena.data(), arena.size(), hipMemcpyHostToDevice, c->stream));
+        }
+        HIP_TRY(hipMemcpyAsync(c->dSrgbLut.ptr, lut, sizeof(lut), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->texturesDirty = false;
+        c->materialsDirty = true;  // texture table indices may have moved
+    }
+    if (c->materialsDirty) {
+        std::vector<int> slotToTexture(c->textures.size(), -1);
+        int next = 0;
+        for (size_t s = 0; s < c->textures.size(); s++)
+            if (c->textures[s].present) slotToTexture[s] = next++;
+        std::vector<DevMaterial> packed;
+        std::string err = PackMaterials(c->materials.data(), c->materials.size(), c->textures.size(), slotToTexture, packed);
+        if (!err.empty()) return fail(PT_ERR_SCENE, err);
+        HIP_TRY(c->dMaterials.ensure(packed.size() * sizeof(DevMaterial)));
+        HIP_TRY(hipMemcpyAsync(c->dMaterials.ptr, packed.data(), packed.size() * sizeof(DevMaterial), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->materialsDirty = false;
+    }
+    if (c->envDirty) {
+        HIP_TRY(c->dEnvColorPdf.ensure(c->envColorPdf.size() * sizeof(float)));
+        HIP_TRY(c->dEnvSample.ensure(c->envSample.size() * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(c->dEnvColorPdf.ptr, c->envColorPdf.data(), c->envColorPdf.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->dEnvSample.ptr, c->envSample.data(), c->envSample.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->envDirty = false;
+    }
+    return PT_OK;
+}
+
+int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t frameStride, bool counted)
+{
+    if (!c) return fail(PT_ERR_INVALID, "null context");
+    if (frameCount == 0) return PT_OK;
+    if (frameFirst == 0) return fail(PT_ERR_INVALID, "FrameCount starts at 1 (weight 1/FrameCount)");
+    if (frameStride == 0) return fail(PT_ERR_INVALID, "frame_stride must be >= 1");
+    DeviceGuard guard(c->device);
+    int rc = syncScene(c);
+    if (rc != PT_OK) return rc;
+
+    const pt_params& u = c->params;
+    DevParams P{};
+    Inverse4(u.view_matrix, P.invView);
+    std::memcpy(P.invProj, u.inv_proj_matrix, 64);
+    std::memcpy(P.view, u.view_matrix, 64);
+    P.frameW = (float)c->width;
+    P.frameH = (float)c->height;
+    P.width = (uint32_t)c->width;
+    P.height = (uint32_t)c->height;
+    P.antiAliasing = u.anti_aliasing_enabled;
+    P.focalLength = u.focal_length;
+    P.apertureSize = u.aperture_size;
+    P.apertureShapeX = u.aperture_shape[0];
+    P.apertureShapeY = u.aperture_shape[1];
+    const float mods[12] = {u.specular_modifier,   u.specular_tint_modifier,  u.metallic_modifier,
+                            u.roughness_modifier,  u.subsurface_modifier,     u.anisotropy_modifier,
+                            u.sheen_roughness_modifier, u.sheen_tint_modifier, u.clearcoat_modifier,
+                            u.clearcoat_roughness_modifier, u.refraction_modifier, u.transmission_modifier};
+    std::memcpy(P.modifiers, mods, sizeof(mods));
+    P.maxBounces = u.max_bounces ? u.max_bounces : 3u;
+    P.accumulateMode = u.accumulate_mode;
+    P.frameFirst = frameFirst;
+    P.frameCount = frameCount;
+    P.frameStride = frameStride;
+    P.hdriW = (float)c->envW;
+    P.hdriH = (float)c->envH;
+    P.envW = c->envW;
+    P.envH = c->envH;
+    P.rootRef = c->rootRef;
+    P.tilesX = (uint32_t)((c->width + 15) / 16);
+    P.tilesY = (uint32_t)((c->height + 15) / 16);
+
+    DevScene S{};
+    S.nodes = (const DevNode*)c->dNodes.ptr;
+    S.triangles = (const DevTriangle*)c->dTriangles.ptr;
+    S.shading = (const DevShading*)c->dShading.ptr;
+    S.materials = (const DevMaterial*)c->dMaterials.ptr;
+    S.textures = (const DevTexture*)c->dTextures.ptr;
+    S.texels = (const unsigned char*)c->dTexels.ptr;
+    S.srgbLut = (const float*)c->dSrgbLut.ptr;
+    S.envColorPdf = (const float4*)c->dEnvColorPdf.ptr;
+    S.envSample = (const float2*)c->dEnvSample.ptr;
+
+    HIP_TRY(hipMemsetAsync(c->dCounters.ptr, 0, sizeof(DevCounters), c->stream));
+    const dim3 grid(P.tilesX * P.tilesY), block(kBlockThreads);
+    DevCounters* ctr = (DevCounters*)c->dCounters.ptr;
+    float4 *i0 = imagePtr(c, 0), *i1 = imagePtr(c, 1), *i2 = imagePtr(c, 2);
+    HIP_TRY(hipEventRecord(c->evStart, c->stream));
+    const bool deep = c->maxDepth > 32;
+    if (counted) {
+        if (deep)
+            hipLaunchKernelGGL((renderKernel<64, true>), grid, block, 0, c->stream, P, S, i0, i1, i2, ctr);
+        else
+            hipLaunchKernelGGL((renderKernel<32, true>), grid, block, 0, c->stream, P, S, i0, i1, i2, ctr);
+    } else {
+        if (deep)
+            hipLaunchKernelGGL((renderKernel<64, false>), grid, block, 0, c->stream, P, S, i0, i1, i2, ctr);
+        else
+            hipLaunchKernelGGL((renderKernel<32, false>), grid, block, 0, c->stream, P, S, i0, i1, i2, ctr);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->evStop, c->stream));
+    c->timed = true;
+    return PT_OK;
+}
+
+}  // namespace
+
+// ================================================================================ C ABI
+extern "C" {
+
+const char* pt_last_error(void) { return g_lastError.c_str(); }
+
+int pt_create(int device, int width, int height, pt_ctx** out)
+{
+    if (!out) return fail(PT_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || width > 32768 || height > 32768)
+        return fail(PT_ERR_INVALID, "image size must be within 1..32768");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(PT_ERR_DEVICE, "no HIP device available (this library has no CPU rendering path)");
+    if (device < 0 || device >= count) return fail(PT_ERR_INVALID, "device index out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PT_ERR_DEVICE, std::string("kernels are built for gfx950 only; device is ") + prop.gcnArchName);
+    DeviceGuard guard(device);
+    std::unique_ptr<pt_ctx> c(new (std::nothrow) pt_ctx());
+    if (!c) return fail(PT_ERR_NOMEM, "out of host memory");
+    c->device = device;
+    c->width = width;
+    c->height = height;
+    HIP_TRY(hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking));
+    c->stream = c->ownStream;
+    HIP_TRY(hipEventCreate(&c->evStart));
+    HIP_TRY(hipEventCreate(&c->evStop));
+    const size_t imageBytes = (size_t)width * height * sizeof(float4);
+    for (int i = 0; i < 3; i++) {
+        HIP_TRY(c->dImages[i].ensure(imageBytes));
+        HIP_TRY(hipMemsetAsync(c->dImages[i].ptr, 0, imageBytes, c->stream));
+    }
+    HIP_TRY(c->dCounters.ensure(sizeof(DevCounters)));
+    HIP_TRY(hipMemsetAsync(c->dCounters.ptr, 0, sizeof(DevCounters), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *out = c.release();
+    return PT_OK;
+}
+
+void pt_destroy(pt_ctx* c)
+{
+    if (!c) return;
+    DeviceGuard guard(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DeviceBuffer* all[] = {&c->dNodes, &c->dTriangles, &c->dShading, &c->dMaterials, &c->dTextures, &c->dTexels,
+                           &c->dSrgbLut, &c->dEnvColorPdf, &c->dEnvSample, &c->dImages[0], &c->dImages[1],
+                           &c->dImages[2], &c->dCounters};
+    for (DeviceBuffer* b : all) b->release();
+    if (c->evStart) (void)hipEventDestroy(c->evStart);
+    if (c->evStop) (void)hipEventDestroy(c->evStop);
+    if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
+    delete c;
+}
+
+int pt_set_stream(pt_ctx* c, void* hipStream)
+{
+    if (!c) return fail(PT_ERR_INVALID, "null context");
+    DeviceGuard guard(c->device);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = hipStream ? (hipStream_t)hipStream : c->ownStream;
+    return PT_OK;
+}
+
+int pt_bind_images(pt_ctx* c, void* dRadiance, void* dAlbedo, void* dNormal)
+{
+    if (!c) return fail(PT_ERR_INVALID, "null context");
+    const int given = (dRadiance != nullptr) + (dAlbedo != nullptr) + (dNormal != nullptr);
+    if (given != 0 && given != 3) return fail(PT_ERR_INVALID, "bind all three images or none");
+    void* ptrs[3] = {dRadiance, dAlbedo, dNormal};
+    for (int i = 0; i < 3; i++) {
+        if (ptrs[i] && ((uintptr_t)ptrs[i] % 16) != 0) return fail(PT_ERR_INVALID, "image pointers must be 16-byte aligned");
+        if (ptrs[i]) {
+            hipPointerAttribute_t attr;
+            hipError_t e = hipPointerGetAttributes(&attr, ptrs[i]);
+            if (e != hipSuccess || attr.type != hipMemoryTypeDevice || attr.device != c->device) {
+                (void)hipGetLastError();
+                return fail(PT_ERR_INVALID, "image pointer is not device memory of the context's GPU");
+            }
+        }
+    }
+    for (int i = 0; i < 3; i++) c->bound[i] = (float4*)ptrs[i];
+    return PT_OK;
+}
+
+int pt_upload_nodes(pt_ctx* c, const void* nodes48, size_t count)
+{
+    if (!c || !nodes48) return fail(PT_ERR_INVALID, "null argument");
+    if (count < 2) return fail(PT_ERR_INVALID, "need the dummy node 0 and the root node 1");
+    const RefNodeAlign* p = (const RefNodeAlign*)nodes48;
+    c->nodes.assign(p, p + count);
+    c->geometryDirty = true;
+    return PT_OK;
+}
+
+int pt_upload_primitives(pt_ctx* c, const void* prims112, size_t count)
+{
+    if (!c || !prims112) return fail(PT_ERR_INVALID, "null argument");
+    if (count == 0) return fail(PT_ERR_INVALID, "no primitives");
+    const RefPrimitiveAlign* p = (const RefPrimitiveAlign*)prims112;
+    c->prims.assign(p, p + count);
+    c->geometryDirty = true;
+    return PT_OK;
+}
+
+int pt_upload_materials(pt_ctx* c, const void* mats176, size_t count)
+{
+    if (!c || !mats176) return fail(PT_ERR_INVALID, "null argument");
+    if (count == 0) return fail(PT_ERR_INVALID, "no materials");
+    const RefMaterialAlign* p = (const RefMaterialAlign*)mats176;
+    c->materials.assign(p, p + count);
+    c->materialsDirty = true;
+    c->geometryDirty = true;  // meshIndex range is validated against the material count
+    return PT_OK;
+}
+
+int pt_upload_texture(pt_ctx* c, int slot, int width, int height, int channels, int isSrgb, int isFloat, const void* texels)
+{
+    if (!c || !texels) return fail(PT_ERR_INVALID, "null argument");
+    if (slot < 1 || slot > 65535) return fail(PT_ERR_INVALID, "texture slot must be within 1..65535");
+    if (width <= 0 || height <= 0 || width > 65536 || height > 65536) return fail(PT_ERR_INVALID, "bad texture size");
+    if (channels < 1 || channels > 4) return fail(PT_ERR_INVALID, "channels must be 1..4");
+    if (isSrgb && isFloat) return fail(PT_ERR_INVALID, "sRGB decoding applies to 8-bit textures only");
+    if ((size_t)slot >= c->textures.size()) c->textures.resize((size_t)slot + 1);
+    HostTexture& t = c->textures[(size_t)slot];
+    t.width = width;
+    t.height = height;
+    t.channels = channels;
+    t.format = isFloat ? 2 : (isSrgb ? 1 : 0);
+    const size_t bytes = (size_t)width * height * channels * (isFloat ? 4 : 1);
+    t.bytes.assign((const unsigned char*)texels, (const unsigned char*)texels + bytes);
+    t.present = true;
+    c->texturesDirty = true;
+    return PT_OK;
+}
+
+int pt_upload_environment_with_cache(pt_ctx* c, const float* hdri, const float* cache, int width, int height)
+{
+    if (!c || !hdri || !cache) return fail(PT_ERR_INVALID, "null argument");
+    if (width <= 0 || height <= 0 || width > 32768 || height > 32768) return fail(PT_ERR_INVALID, "bad HDRI size");
+    const size_t n = (size_t)width * height;
+    c->envColorPdf.resize(n * 4);
+    c->envSample.resize(n * 2);
+    for (size_t i = 0; i < n; i++) {
+        c->envColorPdf[4 * i + 0] = hdri[3 * i + 0];
+        c->envColorPdf[4 * i + 1] = hdri[3 * i + 1];
+        c->envColorPdf[4 * i + 2] = hdri[3 * i + 2];
+        c->envColorPdf[4 * i + 3] = cache[3 * i + 2];
+        c->envSample[2 * i + 0] = cache[3 * i + 0];
+        c->envSample[2 * i + 1] = cache[3 * i + 1];
+    }
+    c->envW = width;
+    c->envH = height;
+    c->envDirty = true;
+    return PT_OK;
+}
+
+int pt_upload_environment(pt_ctx* c, const float* hdri, int width, int height)
+{
+    if (!c || !hdri) return fail(PT_ERR_INVALID, "null argument");
+    if (width <= 0 || height <= 0 || width > 32768 || height > 32768) return fail(PT_ERR_INVALID, "bad HDRI size");
+    std::vector<float> cache((size_t)width * height * 3);
+    CalculateHdriCache(hdri, width, height, cache.data());
+    return pt_upload_environment_with_cache(c, hdri, cache.data(), width, height);
+}
+
+int pt_add_model(pt_ctx* c, const void* vertices32, size_t vertexCount, const void* indices, size_t indexCount,
+                 int indexBytes, const void* material176)
+{
+    if (!c || !vertices32 || !indices || !material176) return fail(PT_ERR_INVALID, "null argument");
+    if (indexBytes != 1 && indexBytes != 2 && indexBytes != 4)
+        return fail(PT_ERR_INVALID, "EBO Type not supported!");  // PathTracingRenderer.cpp:281
+    if (indexCount % 3 != 0) return fail(PT_ERR_INVALID, "index count is not a multiple of 3");
+    PendingModel m;
+    m.vertices.assign((const RefVertex*)vertices32, (const RefVertex*)vertices32 + vertexCount);
+    m.indices.resize(indexCount);
+    for (size_t i = 0; i < indexCount; i++) {
+        uint32_t v = indexBytes == 1 ? ((const uint8_t*)indices)[i]
+                     : indexBytes == 2 ? ((const uint16_t*)indices)[i]
+                                       : ((const uint32_t*)indices)[i];
+        if (v >= vertexCount) return fail(PT_ERR_INVALID, "index " + std::to_string(v) + " exceeds the vertex count");
+        m.indices[i] = v;
+    }
+    std::memcpy(&m.material, material176, sizeof(RefMaterialAlign));
+    c->models.push_back(std::move(m));
+    return PT_OK;
+}
+
+int pt_clear_models(pt_ctx* c)
+{
+    if (!c) return fail(PT_ERR_INVALID, "null context");
+    c->models.clear();
+    return PT_OK;
+}
+
+int pt_process_buffers(pt_ctx* c)
+{
+    if (!c) return fail(PT_ERR_INVALID, "null context");
+    if (c->models.empty()) return fail(PT_ERR_STATE, "no models added");
+    size_t triangles = 0;
+    for (const PendingModel& m : c->models) triangles += m.indices.size() / 3;
+    if (triangles == 0) return fail(PT_ERR_STATE, "models contain no triangles");
+    std::vector<RefPrimitive> soup(triangles);
+    std::vector<RefMaterialAlign> mats;
+    size_t at = 0;
+    uint32_t meshIndex = 0;
+    for (const PendingModel& m : c->models) {
+        AssemblePrimitives(m.vertices.data(), m.indices.data(), m.indices.size(), 4, meshIndex, soup.data() + at);
+        at += m.indices.size() / 3;
+        mats.push_back(m.material);
+        meshIndex++;
+    }
+    std::vector<RefNode> nodes;
+    BuildBvhWithSah(soup.data(), soup.size(), 4, nodes);
+    std::vector<RefNodeAlign> nodesAligned(nodes.size());
+    std::vector<RefPrimitiveAlign> primsAligned(soup.size());
+    AlignNodes(nodes.data(), nodes.size(), nodesAligned.data());
+    AlignPrimitives(soup.data(), soup.size(), primsAligned.data());
+    int rc = pt_upload_materials(c, mats.data(), mats.size());
+    if (rc != PT_OK) return rc;
+    rc = pt_upload_nodes(c, nodesAligned.data(), nodesAligned.size());
+    if (rc != PT_OK) return rc;
+    return pt_upload_primitives(c, primsAligned.data(), primsAligned.size());
+}
+
+int pt_build_bvh_sah(void* prims100, size_t count, int leafSize, void* nodes40Out, size_t nodeCapacity, size_t* nodeCountOut)
+{
+    if (!prims100 || !nodes40Out || !nodeCountOut) return fail(PT_ERR_INVALID, "null argument");
+    if (leafSize < 1) return fail(PT_ERR_INVALID, "leaf_size must be >= 1");
+    if (count > 0x7fffffffu) return fail(PT_ERR_INVALID, "too many primitives");
+    std::vector<RefNode> nodes;
+    BuildBvhWithSah((RefPrimitive*)prims100, count, leafSize, nodes);
+    if (nodes.size() > nodeCapacity) return fail(PT_ERR_INVALID, "node_capacity too small: need " + std::to_string(nodes.size()));
+    std::memcpy(nodes40Out, nodes.data(), nodes.size() * sizeof(RefNode));
+    *nodeCountOut = nodes.size();
+    return PT_OK;
+}
+
+int pt_assemble_primitives(const void* vertices32, size_t vertexCount, const void* indices, size_t indexCount,
+                           int indexBytes, uint32_t meshIndex, void* prims100Out)
+{
+    if (!vertices32 || !indices || !prims100Out) return fail(PT_ERR_INVALID, "null argument");
+    if (indexBytes != 1 && indexBytes != 2 && indexBytes != 4) return fail(PT_ERR_INVALID, "EBO Type not supported!");
+    for (size_t i = 0; i < indexCount; i++) {
+        uint32_t v = indexBytes == 1 ? ((const uint8_t*)indices)[i]
+                     : indexBytes == 2 ? ((const uint16_t*)indices)[i]
+                                       : ((const uint32_t*)indices)[i];
+        if (v >= vertexCount) return fail(PT_ERR_INVALID, "index " + std::to_string(v) + " exceeds the vertex count");
+    }
+    AssemblePrimitives((const RefVertex*)vertices32, indices, indexCount, indexBytes, meshIndex, (RefPrimitive*)prims100Out);
+    return PT_OK;
+}
+
+int pt_align_nodes(const void* nodes40, size_t count, void* nodes48Out)
+{
+    if (!nodes40 || !nodes48Out) return fail(PT_ERR_INVALID, "null argument");
+    AlignNodes((const RefNode*)nodes40, count, (RefNodeAlign*)nodes48Out);
+    return PT_OK;
+}
+
+int pt_align_primitives(const void* prims100, size_t count, void* prims112Out)
+{
+    if (!prims100 || !prims112Out) return fail(PT_ERR_INVALID, "null argument");
+    AlignPrimitives((const RefPrimitive*)prims100, count, (RefPrimitiveAlign*)prims112Out);
+    return PT_OK;
+}
+
+int pt_calculate_hdri_cache(const float* hdri, int width, int height, float* cacheOut)
+{
+    if (!hdri || !cacheOut) return fail(PT_ERR_INVALID, "null argument");
+    if (width <= 0 || height <= 0) return fail(PT_ERR_INVALID, "bad HDRI size");
+    CalculateHdriCache(hdri, width, height, cacheOut);
+    return PT_OK;
+}
+
+void pt_look_at(const float eye[3], const float center[3], const float up[3], float out16[16]) { LookAt(eye, center, up, out16); }
+void pt_perspective(float fovy, float aspect, float zNear, float zFar, float out16[16]) { Perspective(fovy, aspect, zNear, zFar, out16); }
+void pt_inverse4(const float in16[16], float out16[16]) { Inverse4(in16, out16); }
+
+void pt_default_params(int width, int height, pt_params* out)
+{
+    if (!out) return;
+    std::memset(out, 0, sizeof(*out));
+    const float eye[3] = {-2.5f, 1.0f, 0.0f}, center[3] = {0.0f, 0.0f, 0.0f}, up[3] = {0.0f, 1.0f, 0.0f};
+    LookAt(eye, center, up, out->view_matrix);
+    Perspective(1.57f, (float)width / (float)height, 0.01f, 1000.0f, out->proj_matrix);
+    Inverse4(out->proj_matrix, out->inv_proj_matrix);
+    out->frame_count = 1;
+    out->frame_dimensions[0] = (float)width;
+    out->frame_dimensions[1] = (float)height;
+    out->anti_aliasing_enabled = 1;
+    out->focal_length = 3.5f;
+    out->aperture_size = 0.0f;
+    out->aperture_shape[0] = 1.0f;
+    out->aperture_shape[1] = 1.0f;
+    out->max_bounces = 3;
+    out->accumulate_mode = PT_ACCUM_RUNNING_MEAN;
+}
+
+int pt_set_params(pt_ctx* c, const pt_params* p)
+{
+    if (!c || !p) return fail(PT_ERR_INVALID, "null argument");
+    if ((p->frame_dimensions[0] != 0.0f || p->frame_dimensions[1] != 0.0f) &&
+        (p->frame_dimensions[0] != (float)c->width || p->frame_dimensions[1] != (float)c->height))
+        return fail(PT_ERR_INVALID, "FrameDimensions does not match the context size");
+    if (p->accumulate_mode > PT_ACCUM_SUM) return fail(PT_ERR_INVALID, "unknown accumulate_mode");
+    if (p->max_bounces > 1024) return fail(PT_ERR_INVALID, "max_bounces above 1024");
+    c->params = *p;
+    c->haveParams = true;
+    return PT_OK;
+}
+
+int pt_clear(pt_ctx* c)
+{
+    if (!c) return fail(PT_ERR_INVALID, "null context");
+    DeviceGuard guard(c->device);
+    const size_t imageBytes = (size_t)c->width * c->height * sizeof(float4);
+    for (int i = 0; i < 3; i++) HIP_TRY(hipMemsetAsync(imagePtr(c, i), 0, imageBytes, c->stream));
+    return PT_OK;
+}
+
+int pt_dispatch(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t frameStride)
+{
+    return dispatchImpl(c, frameFirst, frameCount, frameStride, false);
+}
+
+int pt_dispatch_counted(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t frameStride)
+{
+    return dispatchImpl(c, frameFirst, frameCount, frameStride, true);
+}
+
+int pt_scale_images(pt_ctx* c, float scale)
+{
+    if (!c) return fail(PT_ERR_INVALID, "null context");
+    DeviceGuard guard(c->device);
+    const size_t n = (size_t)c->width * c->height;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(scaleImagesKernel, dim3(blocks), dim3(256), 0, c->stream, imagePtr(c, 0), imagePtr(c, 1), imagePtr(c, 2), n, scale);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+int pt_synchronize(pt_ctx* c)
+{
+    if (!c) return fail(PT_ERR_INVALID, "null context");
+    DeviceGuard guard(c->device);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_read_image(pt_ctx* c, int which, float* rgbaOut)
+{
+    if (!c || !rgbaOut) return fail(PT_ERR_INVALID, "null argument");
+    if (which < 0 || which > 2) return fail(PT_ERR_INVALID, "image index must be 0..2");
+    DeviceGuard guard(c->device);
+    const size_t imageBytes = (size_t)c->width * c->height * sizeof(float4);
+    HIP_TRY(hipMemcpyAsync(rgbaOut, imagePtr(c, which), imageBytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_get_stats(pt_ctx* c, pt_stats* out)
+{
+    if (!c || !out) return fail(PT_ERR_INVALID, "null argument");
+    DeviceGuard guard(c->device);
+    DevCounters h{};
+    HIP_TRY(hipMemcpyAsync(&h, c->dCounters.ptr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    out->samples = h.samples;
+    out->rays_closest = h.raysClosest;
+    out->rays_any = h.raysAny;
+    out->node_visits = h.nodeVisits;
+    out->triangle_tests = h.triangleTests;
+    out->closest_hits = h.closestHits;
+    out->max_stack_depth = h.maxStack;
+    out->reserved = 0;
+    return PT_OK;
+}
+
+int pt_last_dispatch_ms(pt_ctx* c, float* msOut)
+{
+    if (!c || !msOut) return fail(PT_ERR_INVALID, "null argument");
+    if (!c->timed) return fail(PT_ERR_STATE, "no dispatch yet");
+    DeviceGuard guard(c->device);
+    HIP_TRY(hipEventSynchronize(c->evStop));
+    HIP_TRY(hipEventElapsedTime(msOut, c->evStart, c->evStop));
+    return PT_OK;
+}
+
+int pt_scene_bytes(pt_ctx* c, uint64_t* nodeBytes, uint64_t* triangleBytes, uint64_t* shadingBytes)
+{
+    if (!c) return fail(PT_ERR_INVALID, "null context");
+    if (nodeBytes) *nodeBytes = c->nodeBytes;
+    if (triangleBytes) *triangleBytes = c->triangleBytes;
+    if (shadingBytes) *shadingBytes = c->shadingBytes;
+    return PT_OK;
+}
+
+// Test hook (not part of the drop-in surface): evaluates one float32 building block of the
+// kernels element-wise on the device.  fn: 0 sin, 1 cos, 2 asin, 3 atan2(a,b), 4 pow(a,b),
+// 5 min, 6 max, 7 a/b, 8 sqrt, 9 1/sqrt.
+int pt_debug_eval_math(int device, int fn, const float* a, const float* b, float* out, size_t n)
+{
+    if (!a || !b || !out) return fail(PT_ERR_INVALID, "null argument");
+    if (n == 0) return PT_OK;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count)
+        return fail(PT_ERR_DEVICE, "no such HIP device");
+    DeviceGuard guard(device);
+    DeviceBuffer da, db, dout;
+    int rc = PT_OK;
+    auto body = [&]() -> int {
+        HIP_TRY(da.ensure(n * 4));
+        HIP_TRY(db.ensure(n * 4));
+        HIP_TRY(dout.ensure(n * 4));
+        HIP_TRY(hipMemcpy(da.ptr, a, n * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(db.ptr, b, n * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(evalMathKernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, fn, (const float*)da.ptr,
+                           (const float*)db.ptr, (float*)dout.ptr, n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(out, dout.ptr, n * 4, hipMemcpyDeviceToHost));
+        return PT_OK;
+    };
+    rc = body();
+    da.release();
+    db.release();
+    dout.release();
+    return rc;
+}
+
+}  // extern "C"

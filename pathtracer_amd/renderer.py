@@ -1,0 +1,191 @@
+"""Thin object wrapper over the C ABI: one Renderer = one pt_ctx (one GPU, one stream).
+
+Method names follow the reference host class they stand in for
+(Source/PathTracer/PathTracingRenderer.{h,cpp}: AddPathTracingModel, ClearPathTracingModels,
+ProcessBuffers; PathTracingRenderPass::Render -> dispatch).
+"""
+import ctypes
+
+import numpy as np
+
+from . import lib as _l
+from .lib import Params, Stats, check
+
+RADIANCE, ALBEDO, NORMAL = 0, 1, 2
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Renderer:
+    def __init__(self, width, height, device=0):
+        self._lib = _l.load()
+        self.width, self.height = int(width), int(height)
+        h = ctypes.c_void_p()
+        check(self._lib.pt_create(int(device), self.width, self.height, ctypes.byref(h)))
+        self._h = h
+        self._keep = []
+
+    # ------------------------------------------------------------------ life cycle
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        check(self._lib.pt_set_stream(self._h, ctypes.c_void_p(hip_stream)))
+
+    def bind_images(self, d_radiance, d_albedo, d_normal):
+        """Device pointers (ints) of three width*height*4 float buffers, or three zeros."""
+        check(self._lib.pt_bind_images(self._h, ctypes.c_void_p(d_radiance), ctypes.c_void_p(d_albedo),
+                                       ctypes.c_void_p(d_normal)))
+
+    # ---------------------------------------------------------------- scene upload
+    def upload_nodes(self, nodes48):
+        a = np.ascontiguousarray(nodes48)
+        assert a.nbytes % 48 == 0
+        check(self._lib.pt_upload_nodes(self._h, _ptr(a), a.nbytes // 48))
+
+    def upload_primitives(self, prims112):
+        a = np.ascontiguousarray(prims112)
+        assert a.nbytes % 112 == 0
+        check(self._lib.pt_upload_primitives(self._h, _ptr(a), a.nbytes // 112))
+
+    def upload_materials(self, mats176):
+        a = np.ascontiguousarray(mats176)
+        assert a.nbytes % 176 == 0
+        check(self._lib.pt_upload_materials(self._h, _ptr(a), a.nbytes // 176))
+
+    def upload_texture(self, slot, texels, is_srgb=False):
+        a = np.ascontiguousarray(texels)
+        h, w = a.shape[:2]
+        ch = 1 if a.ndim == 2 else a.shape[2]
+        is_float = a.dtype == np.float32
+        assert is_float or a.dtype == np.uint8
+        check(self._lib.pt_upload_texture(self._h, int(slot), w, h, ch, int(is_srgb), int(is_float), _ptr(a)))
+
+    def upload_environment(self, hdri_rgb, cache_rgb=None):
+        a = np.ascontiguousarray(hdri_rgb, dtype=np.float32)
+        h, w = a.shape[:2]
+        if cache_rgb is None:
+            check(self._lib.pt_upload_environment(self._h, _ptr(a), w, h))
+        else:
+            c = np.ascontiguousarray(cache_rgb, dtype=np.float32)
+            assert c.shape == a.shape
+            check(self._lib.pt_upload_environment_with_cache(self._h, _ptr(a), _ptr(c), w, h))
+
+    # PathTracingRenderer::AddPathTracingModel / ClearPathTracingModels / ProcessBuffers
+    def AddPathTracingModel(self, vertices, indices, material176):
+        v = np.ascontiguousarray(vertices, dtype=np.float32)
+        i = np.ascontiguousarray(indices)
+        m = np.ascontiguousarray(material176)
+        assert m.nbytes == 176 and v.nbytes % 32 == 0
+        check(self._lib.pt_add_model(self._h, _ptr(v), v.nbytes // 32, _ptr(i), i.size, i.dtype.itemsize, _ptr(m)))
+
+    def ClearPathTracingModels(self):
+        check(self._lib.pt_clear_models(self._h))
+
+    def ProcessBuffers(self):
+        check(self._lib.pt_process_buffers(self._h))
+
+    # ------------------------------------------------------------------- per frame
+    def set_params(self, params):
+        check(self._lib.pt_set_params(self._h, ctypes.byref(params)))
+
+    def clear(self):
+        check(self._lib.pt_clear(self._h))
+
+    def dispatch(self, frame_first, frame_count=1, frame_stride=1, counted=False):
+        fn = self._lib.pt_dispatch_counted if counted else self._lib.pt_dispatch
+        check(fn(self._h, int(frame_first), int(frame_count), int(frame_stride)))
+
+    def scale_images(self, scale):
+        check(self._lib.pt_scale_images(self._h, float(scale)))
+
+    def synchronize(self):
+        check(self._lib.pt_synchronize(self._h))
+
+    def read_image(self, which):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        check(self._lib.pt_read_image(self._h, int(which), _ptr(out)))
+        return out
+
+    def stats(self):
+        s = Stats()
+        check(self._lib.pt_get_stats(self._h, ctypes.byref(s)))
+        return s
+
+    def last_dispatch_ms(self):
+        ms = ctypes.c_float()
+        check(self._lib.pt_last_dispatch_ms(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    def scene_bytes(self):
+        a, b, c = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        check(self._lib.pt_scene_bytes(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
+
+
+# ----------------------------------------------------------- host-side helpers (no GPU)
+def default_params(width, height):
+    p = Params()
+    _l.load().pt_default_params(int(width), int(height), ctypes.byref(p))
+    return p
+
+
+def build_bvh_sah(prims100, leaf_size=4):
+    """prims100: (n, 25) float32 view of 100-B records. Returns (reordered prims, nodes (m, 10))."""
+    p = np.ascontiguousarray(prims100, dtype=np.float32).copy()
+    assert p.nbytes % 100 == 0
+    n = p.nbytes // 100
+    nodes = np.zeros((2 * n + 2, 10), np.float32)
+    cnt = ctypes.c_size_t()
+    check(_l.load().pt_build_bvh_sah(_ptr(p), n, int(leaf_size), _ptr(nodes), nodes.shape[0], ctypes.byref(cnt)))
+    return p, nodes[:cnt.value].copy()
+
+
+def assemble_primitives(vertices, indices, mesh_index):
+    v = np.ascontiguousarray(vertices, dtype=np.float32)
+    i = np.ascontiguousarray(indices)
+    out = np.zeros((i.size // 3, 25), np.float32)
+    check(_l.load().pt_assemble_primitives(_ptr(v), v.nbytes // 32, _ptr(i), i.size, i.dtype.itemsize, int(mesh_index), _ptr(out)))
+    return out
+
+
+def align_nodes(nodes40):
+    a = np.ascontiguousarray(nodes40, dtype=np.float32)
+    n = a.nbytes // 40
+    out = np.zeros((n, 12), np.float32)
+    check(_l.load().pt_align_nodes(_ptr(a), n, _ptr(out)))
+    return out
+
+
+def align_primitives(prims100):
+    a = np.ascontiguousarray(prims100, dtype=np.float32)
+    n = a.nbytes // 100
+    out = np.zeros((n, 28), np.float32)
+    check(_l.load().pt_align_primitives(_ptr(a), n, _ptr(out)))
+    return out
+
+
+def calculate_hdri_cache(hdri_rgb):
+    a = np.ascontiguousarray(hdri_rgb, dtype=np.float32)
+    h, w = a.shape[:2]
+    out = np.zeros_like(a)
+    check(_l.load().pt_calculate_hdri_cache(_ptr(a), w, h, _ptr(out)))
+    return out
+
+
+def eval_math(fn, a, b=None, device=0):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.zeros_like(a) if b is None else np.ascontiguousarray(b, dtype=np.float32)
+    out = np.empty_like(a)
+    check(_l.load().pt_debug_eval_math(int(device), int(fn), _ptr(a), _ptr(b), _ptr(out), a.size))
+    return out

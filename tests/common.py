@@ -1,0 +1,29 @@
+"""Shared scene construction for the tests: the same reference-layout buffers go to the product
+(through the C ABI) and to the oracle."""
+import functools
+
+import numpy as np
+
+from pathtracer_amd import renderer as R
+from pathtracer_amd import scenes
+
+
+def soup(recipe_list):
+    meshes, mats = scenes.flatten(recipe_list)
+    parts = [R.assemble_primitives(v, i, k) for k, (v, i) in enumerate(meshes)]
+    return np.concatenate(parts), mats
+
+
+@functools.lru_cache(maxsize=8)
+def built_scene(recipe_name):
+    """-> (nodes48 (n,12) f32, prims112 (m,28) f32, materials) built with the product's host code."""
+    prims100, mats = soup(scenes.recipe(recipe_name))
+    prims_sorted, nodes40 = R.build_bvh_sah(prims100, 4)
+    return R.align_nodes(nodes40), R.align_primitives(prims_sorted), mats
+
+
+@functools.lru_cache(maxsize=4)
+def environment(width=256, height=128):
+    hdri = scenes.sky_hdri(width, height)
+    cache = R.calculate_hdri_cache(hdri)
+    return hdri, cache

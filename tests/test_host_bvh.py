@@ -1,0 +1,112 @@
+"""Host BVH builder: bit-exact against the reference's own BVH.cpp.
+
+Two pins: (1) the FNV-1a-64 hashes the reference builder produced for the reference meshes
+(reference Source/PathTracer/BVH.cpp compiled unmodified with g++/libstdc++, leaf size 4, as called
+at PathTracingRenderer.cpp:575-584); (2) when oracle/_ref/libref_shim.so is present, a direct
+array comparison against that same code on further inputs, including ragged and tiny ones.
+"""
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from pathtracer_amd import renderer as R
+from pathtracer_amd import scenes
+from tests.common import soup
+
+# meshes -> (prims, nodes incl. dummy, root (left, right), hash(nodes), hash(nodes || prims))
+GOLDEN = {
+    ("torus",): (1152, 704, (2, 353), 0x53e08dd365c7c855, 0x64b24732fc9052bd),
+    ("sphere",): (8064, 4832, (2, 2417), 0x035994503fe7f746, 0xe3e55b43877c24f5),
+    ("teapot",): (15704, 9310, (2, 4659), 0x033bada223e11437, 0x9adf312857f275f9),
+    ("torus", "floor"): (1154, 708, (2, 355), 0xaa2e27cffd737b90, 0x6c448aa5890e4660),
+    ("teapot", "floor"): (15706, 9266, (2, 4633), 0x81b98690d56f2388, 0x9a6d94f0867f6996),
+    ("bunny", "floor"): (144048, 92502, (2, 46135), 0xdac003ce21bb035d, 0xc0ff14b656c7d152),
+}
+
+
+def _prims(meshes):
+    return soup([(m, scenes.material()) for m in meshes])[0]
+
+
+@pytest.mark.parametrize("meshes", list(GOLDEN))
+def test_golden_hashes(meshes):
+    nprims, nnodes, root, h_nodes, h_all = GOLDEN[meshes]
+    prims = _prims(meshes)
+    assert prims.shape[0] == nprims
+    sorted_prims, nodes = R.build_bvh_sah(prims, 4)
+    assert nodes.shape[0] == nnodes
+    ni = nodes.view(np.int32)
+    assert (int(ni[1, 0]), int(ni[1, 1])) == root
+    assert np.all(nodes[0].view(np.int32) == 0)  # zeroed dummy node 0
+    h1 = ob.fnv1a64(nodes)
+    assert h1 == h_nodes
+    assert ob.fnv1a64(sorted_prims, h1) == h_all
+
+
+needs_ref = pytest.mark.skipif(ob.ref_lib() is None, reason="oracle/_ref not built (reference absent)")
+
+
+@needs_ref
+@pytest.mark.parametrize("meshes", [("cube",), ("icosphere",), ("sphere", "floor"), ("icosphere", "cube", "floor")])
+def test_matches_reference_build(meshes):
+    prims = _prims(meshes)
+    ours_p, ours_n = R.build_bvh_sah(prims, 4)
+    ref_p, ref_n = ob.ref_build_bvh_sah(prims, 4)
+    assert ours_n.tobytes() == ref_n.tobytes()
+    assert ours_p.tobytes() == ref_p.tobytes()
+
+
+@needs_ref
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 9, 33, 257])
+@pytest.mark.parametrize("leaf", [1, 4])
+def test_ragged_sizes_match_reference(n, leaf):
+    rng = np.random.default_rng(1234 + n)
+    prims = np.zeros((n, 25), np.float32)
+    prims[:, :9] = rng.uniform(-3, 3, (n, 9)).astype(np.float32)
+    # many exact centroid ties and degenerate boxes, the cases an unstable sort is sensitive to
+    prims[::3, :9] = np.round(prims[::3, :9])
+    prims[:, 24] = np.arange(n, dtype=np.uint32).view(np.float32)
+    ours_p, ours_n = R.build_bvh_sah(prims, leaf)
+    ref_p, ref_n = ob.ref_build_bvh_sah(prims, leaf)
+    assert ours_n.tobytes() == ref_n.tobytes()
+    assert ours_p.tobytes() == ref_p.tobytes()
+
+
+@needs_ref
+def test_large_coordinates_hit_cost_cap_like_reference():
+    # Boxes larger than the reference's 114514 cost cap take its median-split fallback
+    rng = np.random.default_rng(7)
+    prims = np.zeros((300, 25), np.float32)
+    prims[:, :9] = rng.uniform(-2e5, 2e5, (300, 9)).astype(np.float32)
+    ours_p, ours_n = R.build_bvh_sah(prims, 4)
+    ref_p, ref_n = ob.ref_build_bvh_sah(prims, 4)
+    assert ours_n.tobytes() == ref_n.tobytes() and ours_p.tobytes() == ref_p.tobytes()
+
+
+def test_parallel_build_is_deterministic():
+    prims = _prims(("teapot", "floor"))
+    a = R.build_bvh_sah(prims, 4)
+    b = R.build_bvh_sah(prims, 4)
+    assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
+
+
+def test_aligned_layouts():
+    prims = _prims(("torus", "floor"))
+    sorted_prims, nodes = R.build_bvh_sah(prims, 4)
+    n48 = R.align_nodes(nodes)
+    p112 = R.align_primitives(sorted_prims)
+    assert n48.shape == (nodes.shape[0], 12) and p112.shape == (prims.shape[0], 28)
+    assert np.array_equal(n48[:, :4].view(np.int32), nodes[:, :4].view(np.int32))
+    assert np.array_equal(n48[:, 4:7], nodes[:, 4:7]) and np.array_equal(n48[:, 8:11], nodes[:, 7:10])
+    assert np.all(n48[:, 7] == 0) and np.all(n48[:, 11] == 0)
+    # {posA,uvA.x} {norA,uvA.y} {posB,uvB.x} {norB,uvB.y} {posC,uvC.x} {norC,uvC.y} meshIndex
+    assert np.array_equal(p112[:, 0:3], sorted_prims[:, 0:3]) and np.array_equal(p112[:, 3], sorted_prims[:, 18])
+    assert np.array_equal(p112[:, 4:7], sorted_prims[:, 9:12]) and np.array_equal(p112[:, 7], sorted_prims[:, 19])
+    assert np.array_equal(p112[:, 8:11], sorted_prims[:, 3:6]) and np.array_equal(p112[:, 11], sorted_prims[:, 20])
+    assert np.array_equal(p112[:, 16:19], sorted_prims[:, 6:9]) and np.array_equal(p112[:, 23], sorted_prims[:, 23])
+    assert np.array_equal(p112[:, 24].view(np.uint32), sorted_prims[:, 24].view(np.uint32))
+    if ob.ref_lib() is not None:
+        lib = ob.ref_lib()
+        assert lib.ref_sizeof_node_align() == 48 and lib.ref_sizeof_prim_align() == 112
+        assert lib.ref_offsetof_node_AA() == 16 and lib.ref_offsetof_node_BB() == 32
+        assert lib.ref_offsetof_prim_mesh() == 96
