@@ -116,6 +116,15 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make -C pathtracer_amd/csrc` (or "
             "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64.so.7 / HSA runtime,
+    # and two copies in one process cannot both open the GPU.  Importing torch first makes the
+    # dynamic loader satisfy libptcore's NEEDED libamdhip64.so.7 with the copy torch already
+    # loaded (same SONAME), so the library shares torch's runtime, streams and device memory.
+    # Without torch the system runtime under /opt/rocm is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
