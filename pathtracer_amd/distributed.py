@@ -1,0 +1,70 @@
+"""Sample-sharded rendering across the GPUs of one node: one process per GPU (torch.distributed,
+backend "nccl" = RCCL over xGMI), the scene replicated, FrameCount values dealt round-robin.
+
+Every (pixel, FrameCount) sample is independent (the shader seeds its RNG with
+pixelIndex + FrameCount * 719393, Shaders/pathtracing.comp:213-214), so rank r of G renders
+FrameCount r+1, r+1+G, r+1+2G, ... over the full frame and the union over ranks is exactly the
+single-GPU sample set.  Ranks accumulate SUMS (PT_ACCUM_SUM) into torch-owned device buffers that
+the kernel writes directly (pt_bind_images); the only data-path collective is one sum all-reduce of
+those buffers per render, after which every rank holds the total and divides by the sample count.
+The reference has no multi-GPU path; this is new.
+"""
+import torch
+
+from . import renderer as R
+
+
+class ShardedRenderer:
+    def __init__(self, width, height, device_index, rank=0, world=1):
+        self.rank, self.world = int(rank), int(world)
+        self.width, self.height = width, height
+        self.device = torch.device("cuda", device_index)
+        self.renderer = R.Renderer(width, height, device=device_index)
+        # Kernels, clears and collectives are all ordered on one torch-owned stream (torch's default
+        # stream is the null stream, which the C ABI reads as "use the context's own stream").
+        self.stream = torch.cuda.Stream(self.device)
+        with torch.cuda.stream(self.stream):
+            # one flat buffer for the three images -> one collective
+            self.images = torch.zeros(3, height, width, 4, device=self.device, dtype=torch.float32)
+            self.total = torch.zeros_like(self.images) if self.world > 1 else self.images
+        self.stream.synchronize()
+        self.renderer.bind_images(*(self.images[k].data_ptr() for k in range(3)))
+        self.renderer.set_stream(self.stream.cuda_stream)
+        self.samples_local = 0
+
+    def set_params(self, params):
+        params.accumulate_mode = 1 if self.world > 1 else params.accumulate_mode
+        self._sum_mode = params.accumulate_mode == 1
+        self.renderer.set_params(params)
+
+    def clear(self):
+        with torch.cuda.stream(self.stream):
+            self.images.zero_()
+        self.samples_local = 0
+
+    def frames_of_step(self, step, spp):
+        """First FrameCount, count and stride of this rank's `spp` samples in step `step`."""
+        first = 1 + self.rank + step * spp * self.world
+        return first, spp, self.world
+
+    def render_step(self, step, spp, counted=False):
+        first, count, stride = self.frames_of_step(step, spp)
+        self.renderer.dispatch(first, count, stride, counted=counted)
+        self.samples_local += count
+
+    def reduce(self):
+        """Sum the accumulation buffers over ranks into `self.total` (one RCCL all-reduce of the
+        three images); this rank's own sums stay intact so rendering can continue.  A no-op on one
+        GPU, where `total` aliases `images`."""
+        if self.world > 1:
+            import torch.distributed as dist
+            with torch.cuda.stream(self.stream):
+                self.total.copy_(self.images)
+                dist.all_reduce(self.total, op=dist.ReduceOp.SUM)
+
+    def resolve(self, total_samples):
+        """Mean images after reduce(): the summed buffers divided by the global sample count."""
+        with torch.cuda.stream(self.stream):
+            out = self.total / float(total_samples) if self._sum_mode else self.total.clone()
+        self.stream.synchronize()
+        return out
