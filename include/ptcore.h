@@ -213,6 +213,11 @@ int pt_last_dispatch_ms(pt_ctx* ctx, float* ms_out);
 /* Device-side sizes of the packed scene, for bandwidth accounting. */
 int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, uint64_t* shading_bytes);
 
+/* Tuning hook, not part of the drop-in surface (no counterpart in the reference): a wave leaves
+ * its traversal phase for the shading phase once fewer than trav_exit_64ths/64 of its live lanes
+ * are still traversing (1..64, default 40). */
+int pt_debug_set_tuning(pt_ctx* ctx, int trav_exit_64ths);
+
 /* Test hook, not part of the drop-in surface (no counterpart in the reference): evaluates one
  * float32 building block of the kernels element-wise on the device so that tests can compare it
  * bit for bit with a CPU evaluation of the same operation sequence.  fn: 0 sin, 1 cos, 2 asin,

@@ -1,17 +1,28 @@
 // HIP kernels of the path-tracing core for gfx950 (wave64).
 //
-// Execution model
+// Execution model: a persistent per-wave state machine.
 //   * One lane owns one pixel for the whole launch and walks that pixel's FrameCount values
 //     (samples) in order.  A wave covers an 8x8 pixel tile, a 256-thread block a 16x16 tile.
-//   * Lanes regenerate: a lane whose path ends accumulates its sample into the images and
-//     immediately starts its next FrameCount, so waves stay full while paths of different
-//     length (Russian roulette, misses, up to max_bounces) run side by side.  A wave leaves
-//     when every lane has finished every sample -- an exit condition every lane reaches.
-//   * BVH traversal keeps the per-lane stack of postponed far children in LDS
-//     (entry k of thread t at word k*256 + t: consecutive lanes hit consecutive banks), the
-//     near child is followed directly without touching the stack.
-//   * The block -> tile map hands each of the 8 XCDs a contiguous band of tiles, so the BVH
-//     sub-trees an XCD's L2 holds are the ones its blocks keep asking for.
+//   * Every lane is in one of four modes: NEW (start the next sample), SHADE (a closest-hit
+//     query finished: shade it), TRAV (a BVH query is in flight), FINISH (accumulate the
+//     sample).  The wave alternates between two phases:
+//       - traversal phase: all TRAV lanes advance their BVH query one step per iteration (one
+//         two-child node, or one triangle of a leaf).  Closest-hit and occlusion (shadow)
+//         queries run in the same loop.  The phase ends when the share of lanes still
+//         traversing falls below a threshold;
+//       - shading phase: the lanes whose query finished shade their hit, or accumulate their
+//         sample and regenerate a primary ray, and re-enter the traversal phase with fresh rays
+//         next to the lanes whose query is still under way (their stack and cursor persist).
+//     Lanes therefore never idle while a neighbour finishes a long traversal or a long path; a
+//     wave leaves when every lane has finished every sample -- a condition every lane reaches.
+//   * One shading pass emits both rays of a bounce.  The shader traces the shadow ray in the
+//     middle of its bounce; everything it computes after an unoccluded shadow ray (light
+//     radiance, BSDF value, MIS weight) does not depend on the ray's outcome, so it is
+//     evaluated up front into a pending contribution that the shadow query merely gates.  The
+//     shadow query and the extension query then run back to back inside the traversal phase
+//     and no surface state has to survive a traversal.
+//   * The per-lane stack of postponed far children lives in LDS (entry k of thread t at word
+//     k*256 + t: consecutive lanes hit consecutive banks); the near child is followed directly.
 //
 // Same results as the reference shader's traversal (intersection.glsl:115-199,230-315):
 // children are visited near-first with the shader's tie rule, leaves are scanned in order
@@ -30,15 +41,6 @@ constexpr int kBlockThreads = 256;
 // distance ties or narrowly beats the current best from being culled with its box.
 constexpr float kPruneMargin = 1.0009765625f;  // 1 + 2^-10
 
-struct TraceCounters {
-    unsigned nodeVisits, triangleTests, maxStack;
-};
-
-struct Hit {
-    float t, u, v;
-    int prim;
-};
-
 // Slab test with the shader's return convention (intersection.glsl:63-77): entry distance, or
 // exit distance when the origin is inside, or -1 on a miss.  t0 is also returned for pruning.
 PT_DEV float hitAabb(v3 o, v3 inv, float minx, float miny, float minz, float maxx, float maxy, float maxz, float& t0out)
@@ -49,95 +51,6 @@ PT_DEV float hitAabb(v3 o, v3 inv, float minx, float miny, float minz, float max
     float t0 = fmax_(fmin_(fx, nx), fmax_(fmin_(fy, ny), fmin_(fz, nz)));
     t0out = t0;
     return (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
-}
-
-// ANY = false: closest hit (returns true and fills `hit` when something was hit).
-// ANY = true : occlusion query, returns on the first triangle hit.
-template <bool ANY, bool COUNT>
-PT_DEV bool traverse(const DevScene& S, int rootRef, v3 o, v3 d, int* stack, Hit& hit, TraceCounters& tc)
-{
-    const v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    float bestT = kFltMax;
-    int bestPrim = -1;
-    float bestU = 0.0f, bestV = 0.0f;
-    int sp = 0;
-    int cur = rootRef;
-    for (;;) {
-        if (cur >= 0) {
-            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
-            const float4 a = np[0], b = np[1], c = np[2], e = np[3];
-            if (COUNT) tc.nodeVisits++;
-            float t0l, t0r;
-            const float dl = hitAabb(o, inv, a.x, a.y, a.z, b.x, b.y, b.z, t0l);
-            const float dr = hitAabb(o, inv, c.x, c.y, c.z, e.x, e.y, e.z, t0r);
-            bool hl = dl > 0.0f, hr = dr > 0.0f;
-            if (!ANY) {
-                const float limit = bestT * kPruneMargin;
-                hl = hl && !(t0l > limit);
-                hr = hr && !(t0r > limit);
-            }
-            const int left = __float_as_int(a.w), right = __float_as_int(b.w);
-            if (hl && hr) {
-                const bool leftFirst = dl < dr;  // intersection.glsl:169-180
-                stack[sp * kBlockThreads] = leftFirst ? right : left;
-                sp++;
-                if (COUNT) tc.maxStack = sp > (int)tc.maxStack ? (unsigned)sp : tc.maxStack;
-                cur = leftFirst ? left : right;
-                continue;
-            }
-            if (hl) {
-                cur = left;
-                continue;
-            }
-            if (hr) {
-                cur = right;
-                continue;
-            }
-        } else {
-            const unsigned bits = ~(unsigned)cur;
-            const unsigned first = bits >> 3, count = (bits & 7u) + 1u;
-            bool found = false;
-            for (unsigned i = 0; i < count; i++) {
-                const float4* tp = reinterpret_cast<const float4*>(S.triangles + first + i);
-                const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-                if (COUNT) tc.triangleTests++;
-                // Moller-Trumbore with the shader's expressions (intersection.glsl:26-40); the edges
-                // and their cross product come precomputed from the host.
-                const v3 n = mk3(q0.w, q1.w, q2.w);
-                const v3 ab = mk3(q1.x, q1.y, q1.z), ac = mk3(q2.x, q2.y, q2.z);
-                const v3 ao = o - mk3(q0.x, q0.y, q0.z);
-                const v3 dao = cross(ao, d);
-                const float det = -dot(d, n);
-                const float invDet = 1.0f / det;
-                const float dst = dot(ao, n) * invDet;
-                const float u = dot(ac, dao) * invDet;
-                const float v = -dot(ab, dao) * invDet;
-                const float w = 1.0f - u - v;
-                const bool ok = det >= 1e-10f && dst >= 0.0f && u >= 0.0f && v >= 0.0f && w >= 0.0f;
-                if (ANY) {
-                    if (ok) {
-                        found = true;
-                        break;
-                    }
-                } else if (ok && dst < bestT) {
-                    bestT = dst;
-                    bestU = u;
-                    bestV = v;
-                    bestPrim = (int)(first + i);
-                }
-            }
-            if (ANY && found) return true;
-        }
-        if (sp == 0) break;
-        sp--;
-        cur = stack[sp * kBlockThreads];
-    }
-    if (ANY) return false;
-    hit.t = bestT;
-    hit.u = bestU;
-    hit.v = bestV;
-    hit.prim = bestPrim;
-    return bestPrim >= 0;
 }
 
 // Primary ray: pathtracing.comp:150-200 (inverse(ViewMatrix) arrives precomputed in P.invView).
@@ -172,16 +85,6 @@ PT_DEV void primaryRay(const DevParams& P, float u, float v, unsigned& rng, v3& 
     }
 }
 
-// blockIdx -> tile index such that blocks sharing an XCD (blockIdx % 8) cover one contiguous
-// band of tiles.  Bijective for any tile count.
-PT_DEV unsigned xcdRemap(unsigned b, unsigned total)
-{
-    const unsigned q = total / 8u, r = total % 8u;
-    const unsigned xcd = b % 8u, local = b / 8u;
-    const unsigned base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
-    return base + local;
-}
-
 PT_DEV float4 accumulate(float4 prev, v3 x, float weight, unsigned mode)
 {
     if (mode == 0u)  // mix(prev, vec4(x, 1), weight): pathtracing.comp:248-260
@@ -189,6 +92,8 @@ PT_DEV float4 accumulate(float4 prev, v3 x, float weight, unsigned mode)
                            mix_(prev.w, 1.0f, weight));
     return make_float4(prev.x + x.x, prev.y + x.y, prev.z + x.z, prev.w + 1.0f);
 }
+
+enum LaneMode : int { kModeNew = 0, kModeShade = 1, kModeTrav = 2, kModeFinish = 3, kModeDone = 4 };
 
 template <int STACK, bool COUNT>
 __global__ __launch_bounds__(kBlockThreads) void renderKernel(DevParams P, DevScene S, float4* __restrict__ radianceImg,
@@ -199,7 +104,9 @@ __global__ __launch_bounds__(kBlockThreads) void renderKernel(DevParams P, DevSc
     const unsigned tid = threadIdx.x;
     int* stack = s_stack + tid;
 
-    const unsigned tile = xcdRemap(blockIdx.x, P.tilesX * P.tilesY);
+    // Consecutive blocks go to different XCDs, so taking tiles in row-major order spreads every
+    // image region -- cheap sky and expensive geometry alike -- evenly over the 8 XCDs.
+    const unsigned tile = blockIdx.x;
     const unsigned tileX = tile % P.tilesX, tileY = tile / P.tilesX;
     const unsigned wave = tid >> 6, lane = tid & 63u;
     const unsigned px = tileX * 16u + (wave & 1u) * 8u + (lane & 7u);
@@ -209,49 +116,51 @@ __global__ __launch_bounds__(kBlockThreads) void renderKernel(DevParams P, DevSc
     const size_t texel = (size_t)py * P.width + px;
 
     unsigned nRays = 0, nShadow = 0, nHits = 0, nSamples = 0;
-    TraceCounters tc{0u, 0u, 0u};
+    unsigned nNodeVisits = 0, nTriTests = 0, maxStack = 0;
 
-    // per-path state
+    // ---- path state
     unsigned k = 0;  // index of the next FrameCount value of this pixel
     const unsigned kEnd = inside ? P.frameCount : 0u;
-    bool active = false;
+    int mode = kModeNew;
     unsigned rng = 0, bounce = 0, frame = 0;
-    v3 ro = splat(0.0f), rd = splat(0.0f);
     v3 radiance = splat(0.0f), throughput = splat(1.0f), f = splat(1.0f);
     v3 albedoRes = splat(0.0f), normalRes = splat(0.0f);
     float pdfBsdf = 1.0f;
+    // ---- ray / traversal state
+    v3 ro = splat(0.0f), rd = splat(0.0f), inv = splat(0.0f);
+    v3 extDir = splat(0.0f);  // direction of the extension ray waiting behind a shadow ray
+    v3 pending = splat(0.0f);  // NEE contribution, added if the shadow ray is unoccluded
+    bool isShadow = false, hasExt = false;
+    int cur = 0, sp = 0;
+    unsigned leafPos = 0, leafEnd = 0;
+    float bestT = kFltMax, bestU = 0.0f, bestV = 0.0f;
+    int bestPrim = -1;
+
+    // Starts a BVH query for the ray (ro, rd).
+    auto beginQuery = [&]() {
+        inv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+        bestT = kFltMax;
+        bestPrim = -1;
+        sp = 0;
+        cur = P.rootRef;
+        leafPos = leafEnd = 0;
+        if (cur < 0) {
+            const unsigned bits = ~(unsigned)cur;
+            leafPos = bits >> 3;
+            leafEnd = leafPos + (bits & 7u) + 1u;
+        }
+        mode = kModeTrav;
+    };
 
     for (;;) {
-        if (!active && k < kEnd) {
-            // main(): pathtracing.comp:206-245
-            frame = P.frameFirst + k * P.frameStride;
-            rng = pixelIndex + frame * 719393u;
-            float u = ((float)px + 0.5f) / P.frameW, v = ((float)py + 0.5f) / P.frameH;
-            if (P.antiAliasing != 0u) {
-                float r1 = randomValue(rng);
-                float r2 = randomValue(rng);
-                u = u + (r1 - 0.5f) / P.frameW;
-                v = v + (r2 - 0.5f) / P.frameH;
-            }
-            primaryRay(P, u, v, rng, ro, rd);
-            radiance = splat(0.0f);
-            throughput = splat(1.0f);
-            f = splat(1.0f);
-            pdfBsdf = 1.0f;
-            albedoRes = splat(0.0f);
-            normalRes = splat(0.0f);
-            bounce = 0;
-            active = true;
-            nSamples++;
-        }
-        if (!__any(active)) break;
-        if (active) {
-            // one iteration of PathTrace's bounce loop (pathtracing.comp:25-140)
-            bool done = false;
-            Hit hit;
-            nRays++;
-            const bool didHit = traverse<false, COUNT>(S, P.rootRef, ro, rd, stack, hit, tc);
-            if (!didHit) {
+        // ================================================================ shading phase
+        if (mode == kModeShade) {
+            // one iteration of PathTrace's bounce loop (pathtracing.comp:25-140) around the
+            // closest-hit result (bestPrim, bestT, bestU, bestV) of the ray (ro, rd)
+            bool hasShadow = false;
+            hasExt = false;
+            mode = kModeFinish;
+            if (bestPrim < 0) {
                 float pdfLight = 0.0f;
                 v3 colorLight = evaluateHdri(S, P.envW, P.envH, P.hdriW, P.hdriH, rd, pdfLight);
                 float misWeight = 1.0f;
@@ -260,22 +169,21 @@ __global__ __launch_bounds__(kBlockThreads) void renderKernel(DevParams P, DevSc
                     misWeight = t / (pdfLight * pdfLight + t);
                 }
                 if (misWeight > 0.0f) radiance = radiance + misWeight * throughput * colorLight * f / pdfBsdf;
-                done = true;
             } else {
                 nHits++;
                 // hit attributes of the winning triangle (intersection.glsl:41-57)
-                const float w = 1.0f - hit.u - hit.v;
-                const v3 P0 = ro + rd * hit.t;
-                const float4* sp = reinterpret_cast<const float4*>(S.shading + hit.prim);
-                const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
-                const float uvx = s0.w * w + s2.w * hit.u + s3.y * hit.v;
-                const float uvy = s1.w * w + s3.x * hit.u + s3.z * hit.v;
-                v3 N = normalize3(mk3(s0.x, s0.y, s0.z) * w + mk3(s1.x, s1.y, s1.z) * hit.u + mk3(s2.x, s2.y, s2.z) * hit.v);
+                const float w = 1.0f - bestU - bestV;
+                const v3 P0 = ro + rd * bestT;
+                const float4* shp = reinterpret_cast<const float4*>(S.shading + bestPrim);
+                const float4 s0 = shp[0], s1 = shp[1], s2 = shp[2], s3 = shp[3], s4 = shp[4];
+                const float uvx = s0.w * w + s2.w * bestU + s3.y * bestV;
+                const float uvy = s1.w * w + s3.x * bestU + s3.z * bestV;
+                v3 N = normalize3(mk3(s0.x, s0.y, s0.z) * w + mk3(s1.x, s1.y, s1.z) * bestU + mk3(s2.x, s2.y, s2.z) * bestV);
                 const v3 Ng = mk3(s4.x, s4.y, s4.z);
                 const unsigned meshIndex = __float_as_uint(s3.w);
                 v3 tangent = splat(0.0f);
                 if (S.materials[meshIndex].tex[kTexNormal] >= 0) {
-                    const float4* tp = reinterpret_cast<const float4*>(S.triangles + hit.prim);
+                    const float4* tp = reinterpret_cast<const float4*>(S.triangles + bestPrim);
                     const float4 q1 = tp[1], q2 = tp[2];
                     const float dBx = s2.w - s0.w, dBy = s3.x - s1.w, dCx = s3.y - s0.w, dCy = s3.z - s1.w;
                     const float invTd = 1.0f / (dBx * dCy - dBy * dCx);
@@ -285,25 +193,23 @@ __global__ __launch_bounds__(kBlockThreads) void renderKernel(DevParams P, DevSc
                 const v3 V = -rd;
                 const Surface surf = makeSurface(me, N, V);
                 radiance = radiance + throughput * surf.emission;
+                const v3 origin = offsetRay(P0, Ng);  // shared by the shadow and the extension ray (:66,:131)
 
-                // next-event estimation towards the HDRI (pathtracing.comp:64-102)
-                const v3 shadowOrigin = offsetRay(P0, Ng);
+                // next-event estimation towards the HDRI (pathtracing.comp:64-102), everything
+                // but the occlusion test itself
                 const v3 Ll = sampleHdri(S, P.envW, P.envH, rng);
                 if (dot(N, Ll) > 0.0f) {
-                    nShadow++;
-                    Hit dummy;
-                    const bool occluded = traverse<true, COUNT>(S, P.rootRef, shadowOrigin, Ll, stack, dummy, tc);
-                    if (!occluded) {
-                        float pdfLight = 0.0f;
-                        v3 colorLight = evaluateHdri(S, P.envW, P.envH, P.hdriW, P.hdriH, Ll, pdfLight);
-                        const Dir dl = makeDir(surf, Ll);
-                        pdfBsdf = 0.0f;
-                        f = evaluateBsdf(surf, dl, pdfBsdf);
-                        if (pdfBsdf > 0.0f) {
-                            float t = pdfLight * pdfLight;
-                            float misWeight = t / (pdfBsdf * pdfBsdf + t);
-                            if (misWeight > 0.0f) radiance = radiance + misWeight * throughput * colorLight * f / pdfLight;
-                        }
+                    hasShadow = true;
+                    pending = splat(0.0f);
+                    float pdfLight = 0.0f;
+                    v3 colorLight = evaluateHdri(S, P.envW, P.envH, P.hdriW, P.hdriH, Ll, pdfLight);
+                    const Dir dl = makeDir(surf, Ll);
+                    float pdfNee = 0.0f;
+                    const v3 fNee = evaluateBsdf(surf, dl, pdfNee);
+                    if (pdfNee > 0.0f) {
+                        float t = pdfLight * pdfLight;
+                        float misWeight = t / (pdfNee * pdfNee + t);
+                        if (misWeight > 0.0f) pending = misWeight * throughput * colorLight * fNee / pdfLight;
                     }
                 }
 
@@ -312,34 +218,173 @@ __global__ __launch_bounds__(kBlockThreads) void renderKernel(DevParams P, DevSc
                 const Dir ds = makeDir(surf, L);
                 pdfBsdf = 0.0f;
                 f = evaluateBsdf(surf, ds, pdfBsdf);
-                if (pdfBsdf <= 0.0f) {
-                    done = true;
-                } else {
+                if (!(pdfBsdf <= 0.0f)) {
                     const float p = fmax_(throughput.x, fmax_(throughput.y, throughput.z));
-                    if (randomValue(rng) >= p) {
-                        done = true;
-                    } else {
+                    if (!(randomValue(rng) >= p)) {
                         throughput = throughput * (1.0f / p);
                         throughput = throughput * (f / pdfBsdf);
-                        ro = shadowOrigin;  // OffsetRay(hitPosition, geometryNormal) again (:131)
-                        rd = L;
                         if (bounce == 0u) {
                             albedoRes = surf.albedo;
                             normalRes = N;
                         }
                         bounce++;
-                        if (bounce >= P.maxBounces) done = true;
+                        hasExt = bounce < P.maxBounces;
                     }
                 }
+                // a shadow query whose pending contribution is exactly zero cannot change the
+                // result and is not issued (a NaN contribution still is)
+                hasShadow = hasShadow && !(pending.x == 0.0f && pending.y == 0.0f && pending.z == 0.0f);
+                if (hasShadow) {
+                    nShadow++;
+                    isShadow = true;
+                    extDir = L;
+                    ro = origin;
+                    rd = Ll;
+                    beginQuery();
+                } else if (hasExt) {
+                    nRays++;
+                    isShadow = false;
+                    hasExt = false;
+                    ro = origin;
+                    rd = L;
+                    beginQuery();
+                }
             }
-            if (done) {
-                const float weight = 1.0f / (float)frame;
-                radianceImg[texel] = accumulate(radianceImg[texel], radiance, weight, P.accumulateMode);
-                albedoImg[texel] = accumulate(albedoImg[texel], albedoRes, weight, P.accumulateMode);
-                normalImg[texel] = accumulate(normalImg[texel], normalRes, weight, P.accumulateMode);
-                active = false;
-                k++;
+        }
+        if (mode == kModeFinish) {
+            const float weight = 1.0f / (float)frame;
+            radianceImg[texel] = accumulate(radianceImg[texel], radiance, weight, P.accumulateMode);
+            albedoImg[texel] = accumulate(albedoImg[texel], albedoRes, weight, P.accumulateMode);
+            normalImg[texel] = accumulate(normalImg[texel], normalRes, weight, P.accumulateMode);
+            k++;
+            mode = kModeNew;
+        }
+        if (mode == kModeNew) {
+            if (k < kEnd) {
+                // main(): pathtracing.comp:206-245
+                frame = P.frameFirst + k * P.frameStride;
+                rng = pixelIndex + frame * 719393u;
+                float u = ((float)px + 0.5f) / P.frameW, v = ((float)py + 0.5f) / P.frameH;
+                if (P.antiAliasing != 0u) {
+                    float r1 = randomValue(rng);
+                    float r2 = randomValue(rng);
+                    u = u + (r1 - 0.5f) / P.frameW;
+                    v = v + (r2 - 0.5f) / P.frameH;
+                }
+                primaryRay(P, u, v, rng, ro, rd);
+                radiance = splat(0.0f);
+                throughput = splat(1.0f);
+                f = splat(1.0f);
+                pdfBsdf = 1.0f;
+                albedoRes = splat(0.0f);
+                normalRes = splat(0.0f);
+                bounce = 0;
+                isShadow = false;
+                hasExt = false;
+                nSamples++;
+                nRays++;
+                beginQuery();
+            } else {
+                mode = kModeDone;
             }
+        }
+        const unsigned long long travMask = __ballot(mode == kModeTrav);
+        if (travMask == 0ull) break;
+        // Leave the traversal phase once fewer than `threshold` lanes are traversing; lanes that
+        // are done for good do not count against the wave.
+        const int alive = __popcll(__ballot(mode != kModeDone));
+        const int threshold = (alive * (int)P.travExitNum + 63) >> 6;
+
+        // ============================================================== traversal phase
+        for (;;) {
+            if (mode == kModeTrav) {
+                bool finished = false;
+                if (leafPos < leafEnd) {
+                    // ---- one triangle of the current leaf: Moller-Trumbore with the shader's
+                    // expressions (intersection.glsl:26-40); edges and normal come precomputed
+                    const float4* tp = reinterpret_cast<const float4*>(S.triangles + leafPos);
+                    const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                    if (COUNT) nTriTests++;
+                    const v3 n = mk3(q0.w, q1.w, q2.w);
+                    const v3 ab = mk3(q1.x, q1.y, q1.z), ac = mk3(q2.x, q2.y, q2.z);
+                    const v3 ao = ro - mk3(q0.x, q0.y, q0.z);
+                    const v3 dao = cross(ao, rd);
+                    const float det = -dot(rd, n);
+                    const float invDet = 1.0f / det;
+                    const float dst = dot(ao, n) * invDet;
+                    const float u = dot(ac, dao) * invDet;
+                    const float v = -dot(ab, dao) * invDet;
+                    const float w = 1.0f - u - v;
+                    const bool ok = det >= 1e-10f && dst >= 0.0f && u >= 0.0f && v >= 0.0f && w >= 0.0f;
+                    if (ok && (isShadow || dst < bestT)) {
+                        bestT = dst;
+                        bestU = u;
+                        bestV = v;
+                        bestPrim = (int)leafPos;
+                    }
+                    leafPos++;
+                    if (isShadow && ok) {
+                        finished = true;  // occluded
+                    } else if (leafPos == leafEnd) {
+                        if (sp == 0) {
+                            finished = true;
+                        } else {
+                            sp--;
+                            cur = stack[sp * kBlockThreads];
+                        }
+                    }
+                } else {
+                    // ---- one interior node: both children's boxes from one 64-byte record
+                    const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
+                    const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+                    if (COUNT) nNodeVisits++;
+                    float t0l, t0r;
+                    const float dl = hitAabb(ro, inv, a.x, a.y, a.z, b.x, b.y, b.z, t0l);
+                    const float dr = hitAabb(ro, inv, c.x, c.y, c.z, e.x, e.y, e.z, t0r);
+                    const float limit = bestT * kPruneMargin;  // bestT stays FLT_MAX for shadow rays
+                    const bool hl = dl > 0.0f && !(t0l > limit);
+                    const bool hr = dr > 0.0f && !(t0r > limit);
+                    const int left = __float_as_int(a.w), right = __float_as_int(b.w);
+                    if (hl && hr) {
+                        const bool leftFirst = dl < dr;  // intersection.glsl:169-180
+                        stack[sp * kBlockThreads] = leftFirst ? right : left;
+                        sp++;
+                        if (COUNT) maxStack = (unsigned)sp > maxStack ? (unsigned)sp : maxStack;
+                        cur = leftFirst ? left : right;
+                    } else if (hl) {
+                        cur = left;
+                    } else if (hr) {
+                        cur = right;
+                    } else if (sp == 0) {
+                        finished = true;
+                    } else {
+                        sp--;
+                        cur = stack[sp * kBlockThreads];
+                    }
+                }
+                if (!finished) {
+                    if (cur < 0 && leafPos == leafEnd) {  // arrived at a leaf reference
+                        const unsigned bits = ~(unsigned)cur;
+                        leafPos = bits >> 3;
+                        leafEnd = leafPos + (bits & 7u) + 1u;
+                        cur = 0;
+                    }
+                } else if (isShadow) {
+                    if (bestPrim < 0) radiance = radiance + pending;  // unoccluded
+                    if (hasExt) {
+                        nRays++;
+                        isShadow = false;
+                        hasExt = false;
+                        rd = extDir;
+                        beginQuery();
+                    } else {
+                        mode = kModeFinish;
+                    }
+                } else {
+                    mode = kModeShade;
+                }
+            }
+            if (__popcll(__ballot(mode == kModeTrav)) < threshold) break;
         }
     }
 
@@ -356,8 +401,8 @@ __global__ __launch_bounds__(kBlockThreads) void renderKernel(DevParams P, DevSc
         atomicAdd(&counters->samples, (unsigned long long)sSamples);
     }
     if (COUNT) {
-        const unsigned sNodes = waveSum(tc.nodeVisits), sTris = waveSum(tc.triangleTests);
-        unsigned m = tc.maxStack;
+        const unsigned sNodes = waveSum(nNodeVisits), sTris = waveSum(nTriTests);
+        unsigned m = maxStack;
         for (int off = 32; off > 0; off >>= 1) {
             unsigned o = __shfl_down(m, off, 64);
             m = o > m ? o : m;

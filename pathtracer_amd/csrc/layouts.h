@@ -79,7 +79,7 @@ enum TextureSlot {
 //
 // A child reference is one int32:
 //   ref >= 0 : index of a DevNode (interior node)
-//   ref <  0 : leaf; bits = ~ref = (first_triangle << 2) | (triangle_count - 1), count 1..4
+//   ref <  0 : leaf; bits = ~ref = (first_triangle << 3) | (triangle_count - 1), count 1..8
 // Leaves therefore need no node fetch at all, and an interior node carries both
 // children's boxes so one 64-B line decides both.
 struct alignas(64) DevNode {
@@ -157,6 +157,7 @@ struct DevParams {
     int32_t envW, envH;
     int32_t rootRef;
     uint32_t tilesX, tilesY;
+    uint32_t travExitNum;  // leave the traversal phase below this many 64ths of the live lanes
 };
 
 struct DevCounters {

@@ -100,6 +100,7 @@ struct pt_ctx {
     float4* bound[3] = {nullptr, nullptr, nullptr};
     int32_t rootRef = 0;
     int maxDepth = 0;
+    uint32_t travExitNum = 40;  // of 64
     size_t nodeBytes = 0, triangleBytes = 0, shadingBytes = 0;
 };
 
@@ -247,6 +248,7 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
     P.rootRef = c->rootRef;
     P.tilesX = (uint32_t)((c->width + 15) / 16);
     P.tilesY = (uint32_t)((c->height + 15) / 16);
+    P.travExitNum = c->travExitNum;
 
     DevScene S{};
     S.nodes = (const DevNode*)c->dNodes.ptr;
@@ -681,6 +683,15 @@ int pt_scene_bytes(pt_ctx* c, uint64_t* nodeBytes, uint64_t* triangleBytes, uint
     if (nodeBytes) *nodeBytes = c->nodeBytes;
     if (triangleBytes) *triangleBytes = c->triangleBytes;
     if (shadingBytes) *shadingBytes = c->shadingBytes;
+    return PT_OK;
+}
+
+// Tuning hook: share of live lanes (in 64ths) below which a wave leaves its traversal phase.
+int pt_debug_set_tuning(pt_ctx* c, int travExit64ths)
+{
+    if (!c) return fail(PT_ERR_INVALID, "null context");
+    if (travExit64ths < 1 || travExit64ths > 64) return fail(PT_ERR_INVALID, "threshold must be 1..64");
+    c->travExitNum = (uint32_t)travExit64ths;
     return PT_OK;
 }
 

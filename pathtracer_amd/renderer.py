@@ -106,6 +106,9 @@ class Renderer:
         fn = self._lib.pt_dispatch_counted if counted else self._lib.pt_dispatch
         check(fn(self._h, int(frame_first), int(frame_count), int(frame_stride)))
 
+    def set_tuning(self, trav_exit_64ths):
+        check(self._lib.pt_debug_set_tuning(self._h, int(trav_exit_64ths)))
+
     def scale_images(self, scale):
         check(self._lib.pt_scale_images(self._h, float(scale)))
 

@@ -115,7 +115,9 @@ def test_small_scene_all_lobes_bit_exact():
     _assert_images_equal(gpu, cpu[:3], cpu[3], "TorusMixed 96x80 4spp")
     st = g.stats()
     assert st.samples == 96 * 80 * 4
-    assert (st.rays_closest, st.rays_any, st.closest_hits) == (cpu[4].rays_closest, cpu[4].rays_any, cpu[4].closest_hits)
+    assert (st.rays_closest, st.closest_hits) == (cpu[4].rays_closest, cpu[4].closest_hits)
+    # shadow queries whose contribution is exactly zero are not issued
+    assert 0 < st.rays_any <= cpu[4].rays_any
     assert st.node_visits <= cpu[4].pair_tests and st.triangle_tests <= cpu[4].triangle_tests
     assert np.isfinite(gpu[0]).all() and gpu[0][..., :3].mean() > 0.01
 
