@@ -215,7 +215,7 @@ int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, 
 
 /* Tuning hook, not part of the drop-in surface (no counterpart in the reference): a wave leaves
  * its traversal phase for the shading phase once fewer than trav_exit_64ths/64 of its live lanes
- * are still traversing (1..64, default 40). */
+ * are still traversing (1..64, default 32). */
 int pt_debug_set_tuning(pt_ctx* ctx, int trav_exit_64ths);
 
 /* Test hook, not part of the drop-in surface (no counterpart in the reference): evaluates one

@@ -96,7 +96,7 @@ PT_DEV float4 accumulate(float4 prev, v3 x, float weight, unsigned mode)
 enum LaneMode : int { kModeNew = 0, kModeShade = 1, kModeTrav = 2, kModeFinish = 3, kModeDone = 4 };
 
 template <int STACK, bool COUNT>
-__global__ __launch_bounds__(kBlockThreads) void renderKernel(DevParams P, DevScene S, float4* __restrict__ radianceImg,
+__global__ __launch_bounds__(kBlockThreads, 4) void renderKernel(DevParams P, DevScene S, float4* __restrict__ radianceImg,
                                                              float4* __restrict__ albedoImg,
                                                              float4* __restrict__ normalImg, DevCounters* counters)
 {
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kBlockThreads) void renderKernel(DevParams P, DevSc
     v3 extDir = splat(0.0f);  // direction of the extension ray waiting behind a shadow ray
     v3 pending = splat(0.0f);  // NEE contribution, added if the shadow ray is unoccluded
     bool isShadow = false, hasExt = false;
-    int cur = 0, sp = 0;
+    int cur = 0, sp = 0, top = 0;  // `top` caches the newest stack entry; LDS holds the older ones
     unsigned leafPos = 0, leafEnd = 0;
     float bestT = kFltMax, bestU = 0.0f, bestV = 0.0f;
     int bestPrim = -1;
@@ -299,15 +299,21 @@ __global__ __launch_bounds__(kBlockThreads) void renderKernel(DevParams P, DevSc
         for (;;) {
             if (mode == kModeTrav) {
                 bool finished = false;
-                if (leafPos < leafEnd) {
+                // One 64-byte fetch per step, whichever record the lane needs: the current leaf's
+                // next triangle (48 B + 16 B of the following record) or the current interior node.
+                // Issuing it before the step diverges puts one memory round trip, not two, on the
+                // wave's critical path.
+                const bool atTriangle = leafPos < leafEnd;
+                const float4* rec = atTriangle ? reinterpret_cast<const float4*>(S.triangles + leafPos)
+                                               : reinterpret_cast<const float4*>(S.nodes + cur);
+                const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+                if (atTriangle) {
                     // ---- one triangle of the current leaf: Moller-Trumbore with the shader's
                     // expressions (intersection.glsl:26-40); edges and normal come precomputed
-                    const float4* tp = reinterpret_cast<const float4*>(S.triangles + leafPos);
-                    const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
                     if (COUNT) nTriTests++;
-                    const v3 n = mk3(q0.w, q1.w, q2.w);
-                    const v3 ab = mk3(q1.x, q1.y, q1.z), ac = mk3(q2.x, q2.y, q2.z);
-                    const v3 ao = ro - mk3(q0.x, q0.y, q0.z);
+                    const v3 n = mk3(r0.w, r1.w, r2.w);
+                    const v3 ab = mk3(r1.x, r1.y, r1.z), ac = mk3(r2.x, r2.y, r2.z);
+                    const v3 ao = ro - mk3(r0.x, r0.y, r0.z);
                     const v3 dao = cross(ao, rd);
                     const float det = -dot(rd, n);
                     const float invDet = 1.0f / det;
@@ -328,26 +334,26 @@ __global__ __launch_bounds__(kBlockThreads) void renderKernel(DevParams P, DevSc
                     } else if (leafPos == leafEnd) {
                         if (sp == 0) {
                             finished = true;
-                        } else {
+                        } else {  // pop: the top entry is kept in a register
+                            cur = top;
                             sp--;
-                            cur = stack[sp * kBlockThreads];
+                            if (sp > 0) top = stack[(sp - 1) * kBlockThreads];
                         }
                     }
                 } else {
                     // ---- one interior node: both children's boxes from one 64-byte record
-                    const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
-                    const float4 a = np[0], b = np[1], c = np[2], e = np[3];
                     if (COUNT) nNodeVisits++;
                     float t0l, t0r;
-                    const float dl = hitAabb(ro, inv, a.x, a.y, a.z, b.x, b.y, b.z, t0l);
-                    const float dr = hitAabb(ro, inv, c.x, c.y, c.z, e.x, e.y, e.z, t0r);
+                    const float dl = hitAabb(ro, inv, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, t0l);
+                    const float dr = hitAabb(ro, inv, r2.x, r2.y, r2.z, r3.x, r3.y, r3.z, t0r);
                     const float limit = bestT * kPruneMargin;  // bestT stays FLT_MAX for shadow rays
                     const bool hl = dl > 0.0f && !(t0l > limit);
                     const bool hr = dr > 0.0f && !(t0r > limit);
-                    const int left = __float_as_int(a.w), right = __float_as_int(b.w);
+                    const int left = __float_as_int(r0.w), right = __float_as_int(r1.w);
                     if (hl && hr) {
                         const bool leftFirst = dl < dr;  // intersection.glsl:169-180
-                        stack[sp * kBlockThreads] = leftFirst ? right : left;
+                        if (sp > 0) stack[(sp - 1) * kBlockThreads] = top;
+                        top = leftFirst ? right : left;
                         sp++;
                         if (COUNT) maxStack = (unsigned)sp > maxStack ? (unsigned)sp : maxStack;
                         cur = leftFirst ? left : right;
@@ -358,8 +364,9 @@ __global__ __launch_bounds__(kBlockThreads) void renderKernel(DevParams P, DevSc
                     } else if (sp == 0) {
                         finished = true;
                     } else {
+                        cur = top;
                         sp--;
-                        cur = stack[sp * kBlockThreads];
+                        if (sp > 0) top = stack[(sp - 1) * kBlockThreads];
                     }
                 }
                 if (!finished) {

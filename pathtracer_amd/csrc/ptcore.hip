@@ -100,7 +100,7 @@ struct pt_ctx {
     float4* bound[3] = {nullptr, nullptr, nullptr};
     int32_t rootRef = 0;
     int maxDepth = 0;
-    uint32_t travExitNum = 40;  // of 64
+    uint32_t travExitNum = 32;  // of 64
     size_t nodeBytes = 0, triangleBytes = 0, shadingBytes = 0;
 };
 
@@ -138,7 +138,7 @@ int syncScene(pt_ctx* c)
         const size_t nb = packed.nodes.size() * sizeof(DevNode), tb = packed.triangles.size() * sizeof(DevTriangle),
                      sb = packed.shading.size() * sizeof(DevShading);
         HIP_TRY(c->dNodes.ensure(nb));
-        HIP_TRY(c->dTriangles.ensure(tb));
+        HIP_TRY(c->dTriangles.ensure(tb + 16));  // a triangle step fetches 64 B from a 48-B record
         HIP_TRY(c->dShading.ensure(sb));
         if (nb) HIP_TRY(hipMemcpyAsync(c->dNodes.ptr, packed.nodes.data(), nb, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->dTriangles.ptr, packed.triangles.data(), tb, hipMemcpyHostToDevice, c->stream));
