@@ -213,10 +213,12 @@ int pt_last_dispatch_ms(pt_ctx* ctx, float* ms_out);
 /* Device-side sizes of the packed scene, for bandwidth accounting. */
 int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, uint64_t* shading_bytes);
 
-/* Tuning hook, not part of the drop-in surface (no counterpart in the reference): a wave leaves
- * its traversal phase for the shading phase once fewer than trav_exit_64ths/64 of its live lanes
- * are still traversing (1..64, default 32). */
-int pt_debug_set_tuning(pt_ctx* ctx, int trav_exit_64ths);
+/* Tuning hook, not part of the drop-in surface (no counterpart in the reference).  key 0: scheduler
+ * (0 = wavefront pipeline, the default; 1 = single-launch megakernel); 1: megakernel traversal-phase
+ * exit threshold in 64ths of the live lanes (default 32); 2: wavefront refill threshold in idle
+ * lanes (default 16); 3: wavefront iterations between read-backs of the live-ray count (default 2);
+ * 4: traverse grid size in blocks (0 = sized from the occupancy query). */
+int pt_debug_set_tuning(pt_ctx* ctx, int key, int value);
 
 /* Test hook, not part of the drop-in surface (no counterpart in the reference): evaluates one
  * float32 building block of the kernels element-wise on the device so that tests can compare it

@@ -1,28 +1,35 @@
 // HIP kernels of the path-tracing core for gfx950 (wave64).
 //
-// Execution model: a persistent per-wave state machine.
-//   * One lane owns one pixel for the whole launch and walks that pixel's FrameCount values
-//     (samples) in order.  A wave covers an 8x8 pixel tile, a 256-thread block a 16x16 tile.
-//   * Every lane is in one of four modes: NEW (start the next sample), SHADE (a closest-hit
-//     query finished: shade it), TRAV (a BVH query is in flight), FINISH (accumulate the
-//     sample).  The wave alternates between two phases:
-//       - traversal phase: all TRAV lanes advance their BVH query one step per iteration (one
-//         two-child node, or one triangle of a leaf).  Closest-hit and occlusion (shadow)
-//         queries run in the same loop.  The phase ends when the share of lanes still
-//         traversing falls below a threshold;
-//       - shading phase: the lanes whose query finished shade their hit, or accumulate their
-//         sample and regenerate a primary ray, and re-enter the traversal phase with fresh rays
-//         next to the lanes whose query is still under way (their stack and cursor persist).
-//     Lanes therefore never idle while a neighbour finishes a long traversal or a long path; a
-//     wave leaves when every lane has finished every sample -- a condition every lane reaches.
+// Two schedulers drive the same per-ray and per-hit device code (same bits out of both):
+//
+//  * WAVEFRONT pipeline (default).  Path state lives in global memory, one slot per pixel.
+//    Each iteration runs two kernels:
+//      - traverseKernel: persistent waves pull tagged ray entries (extension or shadow) from a
+//        queue; a lane that finishes a query fetches the next entry at once, so lanes stay busy
+//        whatever the traversal lengths.  The kernel needs few registers, so many waves per SIMD
+//        hide the pointer-chasing latency.  A finished extension query appends its pixel to the
+//        shade queue; a finished shadow query adds the pending light contribution when unoccluded,
+//        and when it was the path's last ray it accumulates the sample, starts the pixel's next
+//        sample and traces its primary ray on the spot.
+//      - shadeKernel: one lane per shade-queue entry evaluates one bounce (material, NEE
+//        contribution, BSDF sample and evaluation, Russian roulette) at full lane occupancy and
+//        appends the bounce's shadow and extension rays to the next ray queue with
+//        ballot-and-prefix compaction (one atomic per wave).
+//  * MEGAKERNEL (kept for A/B measurements): a persistent per-wave state machine, one lane per
+//    pixel, alternating a traversal phase and a shading phase inside one launch.  Its shading
+//    code pins the whole kernel at ~200 VGPRs (2 waves/SIMD, or 4 with spills), which is what
+//    the wavefront split removes.
+//
+// Common rules
+//   * One pixel's FrameCount values (samples) are traced strictly one after the other, so the
+//     images are accumulated in frame order exactly like frame-by-frame dispatches.
 //   * One shading pass emits both rays of a bounce.  The shader traces the shadow ray in the
 //     middle of its bounce; everything it computes after an unoccluded shadow ray (light
 //     radiance, BSDF value, MIS weight) does not depend on the ray's outcome, so it is
-//     evaluated up front into a pending contribution that the shadow query merely gates.  The
-//     shadow query and the extension query then run back to back inside the traversal phase
-//     and no surface state has to survive a traversal.
+//     evaluated up front into a pending contribution that the shadow query merely gates.
 //   * The per-lane stack of postponed far children lives in LDS (entry k of thread t at word
-//     k*256 + t: consecutive lanes hit consecutive banks); the near child is followed directly.
+//     k*256 + t: consecutive lanes hit consecutive banks) with its newest entry cached in a
+//     register; the near child is followed directly.
 //
 // Same results as the reference shader's traversal (intersection.glsl:115-199,230-315):
 // children are visited near-first with the shader's tie rule, leaves are scanned in order
@@ -52,6 +59,139 @@ PT_DEV float hitAabb(v3 o, v3 inv, float minx, float miny, float minz, float max
     t0out = t0;
     return (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
 }
+
+// ------------------------------------------------------------------------------ BVH query
+struct Query {
+    v3 ro, rd, inv;
+    int cur, sp, top;  // `top` caches the newest stack entry; LDS holds the older ones
+    unsigned leafPos, leafEnd;
+    float bestT, bestU, bestV;
+    int bestPrim;
+    bool isShadow;
+};
+
+struct StepCounters {
+    unsigned nodeVisits, triangleTests, maxStack;
+};
+
+PT_DEV void beginQuery(Query& q, int rootRef, v3 ro, v3 rd, bool isShadow)
+{
+    q.ro = ro;
+    q.rd = rd;
+    q.inv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    q.bestT = kFltMax;
+    q.bestU = 0.0f;
+    q.bestV = 0.0f;
+    q.bestPrim = -1;
+    q.sp = 0;
+    q.top = 0;
+    q.cur = rootRef;
+    q.leafPos = q.leafEnd = 0;
+    q.isShadow = isShadow;
+    if (rootRef < 0) {
+        const unsigned bits = ~(unsigned)rootRef;
+        q.leafPos = bits >> 3;
+        q.leafEnd = q.leafPos + (bits & 7u) + 1u;
+        q.cur = 0;
+    }
+}
+
+// Advances the query by one step -- one triangle of the current leaf, or one interior node (both
+// children's boxes) -- and returns true when the query is complete.  `stack` points at this
+// thread's column of the block's LDS stack.
+template <bool COUNT>
+PT_DEV bool queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc)
+{
+    bool finished = false;
+    // One 64-byte fetch per step, whichever record the lane needs: the current leaf's next
+    // triangle (48 B + 16 B of the following record) or the current interior node.  Issuing it
+    // before the step diverges puts one memory round trip, not two, on the wave's critical path.
+    const bool atTriangle = q.leafPos < q.leafEnd;
+    const float4* rec = atTriangle ? reinterpret_cast<const float4*>(S.triangles + q.leafPos)
+                                   : reinterpret_cast<const float4*>(S.nodes + q.cur);
+    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+    if (atTriangle) {
+        // Moller-Trumbore with the shader's expressions (intersection.glsl:26-40); the edges and
+        // their cross product come precomputed from the host.
+        if (COUNT) sc.triangleTests++;
+        const v3 n = mk3(r0.w, r1.w, r2.w);
+        const v3 ab = mk3(r1.x, r1.y, r1.z), ac = mk3(r2.x, r2.y, r2.z);
+        const v3 ao = q.ro - mk3(r0.x, r0.y, r0.z);
+        const v3 dao = cross(ao, q.rd);
+        const float det = -dot(q.rd, n);
+        const float invDet = 1.0f / det;
+        const float dst = dot(ao, n) * invDet;
+        const float u = dot(ac, dao) * invDet;
+        const float v = -dot(ab, dao) * invDet;
+        const float w = 1.0f - u - v;
+        const bool ok = det >= 1e-10f && dst >= 0.0f && u >= 0.0f && v >= 0.0f && w >= 0.0f;
+        if (ok && (q.isShadow || dst < q.bestT)) {
+            q.bestT = dst;
+            q.bestU = u;
+            q.bestV = v;
+            q.bestPrim = (int)q.leafPos;
+        }
+        q.leafPos++;
+        if (q.isShadow && ok) {
+            finished = true;  // occluded
+        } else if (q.leafPos == q.leafEnd) {
+            if (q.sp == 0) {
+                finished = true;
+            } else {
+                q.cur = q.top;
+                q.sp--;
+                if (q.sp > 0) q.top = stack[(q.sp - 1) * kBlockThreads];
+            }
+        }
+    } else {
+        if (COUNT) sc.nodeVisits++;
+        float t0l, t0r;
+        const float dl = hitAabb(q.ro, q.inv, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, t0l);
+        const float dr = hitAabb(q.ro, q.inv, r2.x, r2.y, r2.z, r3.x, r3.y, r3.z, t0r);
+        const float limit = q.bestT * kPruneMargin;  // bestT stays FLT_MAX for shadow rays
+        const bool hl = dl > 0.0f && !(t0l > limit);
+        const bool hr = dr > 0.0f && !(t0r > limit);
+        const int left = __float_as_int(r0.w), right = __float_as_int(r1.w);
+        if (hl && hr) {
+            const bool leftFirst = dl < dr;  // intersection.glsl:169-180
+            if (q.sp > 0) stack[(q.sp - 1) * kBlockThreads] = q.top;
+            q.top = leftFirst ? right : left;
+            q.sp++;
+            if (COUNT) sc.maxStack = (unsigned)q.sp > sc.maxStack ? (unsigned)q.sp : sc.maxStack;
+            q.cur = leftFirst ? left : right;
+        } else if (hl) {
+            q.cur = left;
+        } else if (hr) {
+            q.cur = right;
+        } else if (q.sp == 0) {
+            finished = true;
+        } else {
+            q.cur = q.top;
+            q.sp--;
+            if (q.sp > 0) q.top = stack[(q.sp - 1) * kBlockThreads];
+        }
+    }
+    if (!finished && q.cur < 0 && q.leafPos == q.leafEnd) {  // arrived at a leaf reference
+        const unsigned bits = ~(unsigned)q.cur;
+        q.leafPos = bits >> 3;
+        q.leafEnd = q.leafPos + (bits & 7u) + 1u;
+        q.cur = 0;
+    }
+    return finished;
+}
+
+// ------------------------------------------------------------------------------ path logic
+struct PathState {
+    unsigned rng, bounce, k, frame;
+    v3 radiance, throughput, f;
+    float pdfBsdf;
+    v3 albedoRes, normalRes;
+};
+
+struct BounceRays {
+    bool hasShadow, hasExt;
+    v3 origin, shadowDir, extDir, pending;
+};
 
 // Primary ray: pathtracing.comp:150-200 (inverse(ViewMatrix) arrives precomputed in P.invView).
 PT_DEV void mulMat4(const float* M, float x, float y, float z, float w, float out[4])
@@ -85,6 +225,116 @@ PT_DEV void primaryRay(const DevParams& P, float u, float v, unsigned& rng, v3& 
     }
 }
 
+// main(): pathtracing.comp:206-245 for sample index ps.k of pixel (px, py).
+PT_DEV void startSample(const DevParams& P, unsigned px, unsigned py, PathState& ps, v3& ro, v3& rd)
+{
+    const unsigned pixelIndex = py * (unsigned)P.frameW + px;  // uint(FrameDimensions.x), :213
+    ps.frame = P.frameFirst + ps.k * P.frameStride;
+    ps.rng = pixelIndex + ps.frame * 719393u;
+    float u = ((float)px + 0.5f) / P.frameW, v = ((float)py + 0.5f) / P.frameH;
+    if (P.antiAliasing != 0u) {
+        float r1 = randomValue(ps.rng);
+        float r2 = randomValue(ps.rng);
+        u = u + (r1 - 0.5f) / P.frameW;
+        v = v + (r2 - 0.5f) / P.frameH;
+    }
+    primaryRay(P, u, v, ps.rng, ro, rd);
+    ps.radiance = splat(0.0f);
+    ps.throughput = splat(1.0f);
+    ps.f = splat(1.0f);
+    ps.pdfBsdf = 1.0f;
+    ps.albedoRes = splat(0.0f);
+    ps.normalRes = splat(0.0f);
+    ps.bounce = 0;
+}
+
+// One iteration of PathTrace's bounce loop (pathtracing.comp:25-140) around the closest-hit
+// result (prim, t, u, v) of the ray (ro, rd); prim < 0 is a miss.  Updates the path state and
+// returns the rays the bounce wants traced.  No ray at all means the path has ended.
+PT_DEV BounceRays shadeBounce(const DevParams& P, const DevScene& S, PathState& ps, v3 ro, v3 rd, int prim, float tHit,
+                              float uHit, float vHit)
+{
+    BounceRays out;
+    out.hasShadow = false;
+    out.hasExt = false;
+    out.origin = out.shadowDir = out.extDir = out.pending = splat(0.0f);
+    if (prim < 0) {
+        float pdfLight = 0.0f;
+        v3 colorLight = evaluateHdri(S, P.envW, P.envH, P.hdriW, P.hdriH, rd, pdfLight);
+        float misWeight = 1.0f;
+        if (ps.bounce > 0u) {
+            float t = ps.pdfBsdf * ps.pdfBsdf;
+            misWeight = t / (pdfLight * pdfLight + t);
+        }
+        if (misWeight > 0.0f) ps.radiance = ps.radiance + misWeight * ps.throughput * colorLight * ps.f / ps.pdfBsdf;
+        return out;
+    }
+    // hit attributes of the winning triangle (intersection.glsl:41-57)
+    const float w = 1.0f - uHit - vHit;
+    const v3 P0 = ro + rd * tHit;
+    const float4* shp = reinterpret_cast<const float4*>(S.shading + prim);
+    const float4 s0 = shp[0], s1 = shp[1], s2 = shp[2], s3 = shp[3], s4 = shp[4];
+    const float uvx = s0.w * w + s2.w * uHit + s3.y * vHit;
+    const float uvy = s1.w * w + s3.x * uHit + s3.z * vHit;
+    v3 N = normalize3(mk3(s0.x, s0.y, s0.z) * w + mk3(s1.x, s1.y, s1.z) * uHit + mk3(s2.x, s2.y, s2.z) * vHit);
+    const v3 Ng = mk3(s4.x, s4.y, s4.z);
+    const unsigned meshIndex = __float_as_uint(s3.w);
+    v3 tangent = splat(0.0f);
+    if (S.materials[meshIndex].tex[kTexNormal] >= 0) {
+        const float4* tp = reinterpret_cast<const float4*>(S.triangles + prim);
+        const float4 q1 = tp[1], q2 = tp[2];
+        const float dBx = s2.w - s0.w, dBy = s3.x - s1.w, dCx = s3.y - s0.w, dCy = s3.z - s1.w;
+        const float invTd = 1.0f / (dBx * dCy - dBy * dCx);
+        tangent = (mk3(q1.x, q1.y, q1.z) * dCy - mk3(q2.x, q2.y, q2.z) * dBy) * invTd;
+    }
+    const MaterialEval me = evaluateMaterial(S, P, meshIndex, uvx, uvy, N, tangent);
+    const v3 V = -rd;
+    const Surface surf = makeSurface(me, N, V);
+    ps.radiance = ps.radiance + ps.throughput * surf.emission;
+    out.origin = offsetRay(P0, Ng);  // shared by the shadow and the extension ray (:66,:131)
+
+    // next-event estimation towards the HDRI (pathtracing.comp:64-102), everything but the
+    // occlusion test itself
+    const v3 Ll = sampleHdri(S, P.envW, P.envH, ps.rng);
+    if (dot(N, Ll) > 0.0f) {
+        float pdfLight = 0.0f;
+        v3 colorLight = evaluateHdri(S, P.envW, P.envH, P.hdriW, P.hdriH, Ll, pdfLight);
+        const Dir dl = makeDir(surf, Ll);
+        float pdfNee = 0.0f;
+        const v3 fNee = evaluateBsdf(surf, dl, pdfNee);
+        if (pdfNee > 0.0f) {
+            float t = pdfLight * pdfLight;
+            float misWeight = t / (pdfNee * pdfNee + t);
+            if (misWeight > 0.0f) out.pending = misWeight * ps.throughput * colorLight * fNee / pdfLight;
+        }
+        // a shadow query whose pending contribution is exactly zero cannot change the result and
+        // is not issued (a NaN contribution still is)
+        out.hasShadow = !(out.pending.x == 0.0f && out.pending.y == 0.0f && out.pending.z == 0.0f);
+        out.shadowDir = Ll;
+    }
+
+    // BSDF sampling, Russian roulette, next ray (pathtracing.comp:104-139)
+    const v3 L = sampleBsdf(surf, ps.rng);
+    const Dir ds = makeDir(surf, L);
+    ps.pdfBsdf = 0.0f;
+    ps.f = evaluateBsdf(surf, ds, ps.pdfBsdf);
+    if (!(ps.pdfBsdf <= 0.0f)) {
+        const float p = fmax_(ps.throughput.x, fmax_(ps.throughput.y, ps.throughput.z));
+        if (!(randomValue(ps.rng) >= p)) {
+            ps.throughput = ps.throughput * (1.0f / p);
+            ps.throughput = ps.throughput * (ps.f / ps.pdfBsdf);
+            if (ps.bounce == 0u) {
+                ps.albedoRes = surf.albedo;
+                ps.normalRes = N;
+            }
+            ps.bounce++;
+            out.hasExt = ps.bounce < P.maxBounces;
+            out.extDir = L;
+        }
+    }
+    return out;
+}
+
 PT_DEV float4 accumulate(float4 prev, v3 x, float weight, unsigned mode)
 {
     if (mode == 0u)  // mix(prev, vec4(x, 1), weight): pathtracing.comp:248-260
@@ -93,12 +343,39 @@ PT_DEV float4 accumulate(float4 prev, v3 x, float weight, unsigned mode)
     return make_float4(prev.x + x.x, prev.y + x.y, prev.z + x.z, prev.w + 1.0f);
 }
 
+struct Images {
+    float4* radiance;
+    float4* albedo;
+    float4* normal;
+};
+
+PT_DEV void accumulateSample(const DevParams& P, const Images& img, size_t texel, const PathState& ps)
+{
+    const float weight = 1.0f / (float)ps.frame;
+    img.radiance[texel] = accumulate(img.radiance[texel], ps.radiance, weight, P.accumulateMode);
+    img.albedo[texel] = accumulate(img.albedo[texel], ps.albedoRes, weight, P.accumulateMode);
+    img.normal[texel] = accumulate(img.normal[texel], ps.normalRes, weight, P.accumulateMode);
+}
+
+PT_DEV unsigned waveSum(unsigned v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+PT_DEV unsigned waveMax(unsigned v)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned o = __shfl_down(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// ================================================================================ megakernel
 enum LaneMode : int { kModeNew = 0, kModeShade = 1, kModeTrav = 2, kModeFinish = 3, kModeDone = 4 };
 
 template <int STACK, bool COUNT>
-__global__ __launch_bounds__(kBlockThreads, 4) void renderKernel(DevParams P, DevScene S, float4* __restrict__ radianceImg,
-                                                             float4* __restrict__ albedoImg,
-                                                             float4* __restrict__ normalImg, DevCounters* counters)
+__global__ __launch_bounds__(kBlockThreads, 4) void renderKernel(DevParams P, DevScene S, Images img, DevCounters* counters)
 {
     __shared__ int s_stack[STACK * kBlockThreads];
     const unsigned tid = threadIdx.x;
@@ -112,184 +389,59 @@ __global__ __launch_bounds__(kBlockThreads, 4) void renderKernel(DevParams P, De
     const unsigned px = tileX * 16u + (wave & 1u) * 8u + (lane & 7u);
     const unsigned py = tileY * 16u + (wave >> 1) * 8u + (lane >> 3);
     const bool inside = px < P.width && py < P.height;
-    const unsigned pixelIndex = py * (unsigned)P.frameW + px;  // uint(FrameDimensions.x), pathtracing.comp:213
     const size_t texel = (size_t)py * P.width + px;
 
     unsigned nRays = 0, nShadow = 0, nHits = 0, nSamples = 0;
-    unsigned nNodeVisits = 0, nTriTests = 0, maxStack = 0;
+    StepCounters sc{0u, 0u, 0u};
 
-    // ---- path state
-    unsigned k = 0;  // index of the next FrameCount value of this pixel
+    PathState ps{};
+    ps.k = 0;
     const unsigned kEnd = inside ? P.frameCount : 0u;
     int mode = kModeNew;
-    unsigned rng = 0, bounce = 0, frame = 0;
-    v3 radiance = splat(0.0f), throughput = splat(1.0f), f = splat(1.0f);
-    v3 albedoRes = splat(0.0f), normalRes = splat(0.0f);
-    float pdfBsdf = 1.0f;
-    // ---- ray / traversal state
-    v3 ro = splat(0.0f), rd = splat(0.0f), inv = splat(0.0f);
-    v3 extDir = splat(0.0f);  // direction of the extension ray waiting behind a shadow ray
+    Query q{};
+    v3 extDir = splat(0.0f);   // direction of the extension ray waiting behind a shadow ray
     v3 pending = splat(0.0f);  // NEE contribution, added if the shadow ray is unoccluded
-    bool isShadow = false, hasExt = false;
-    int cur = 0, sp = 0, top = 0;  // `top` caches the newest stack entry; LDS holds the older ones
-    unsigned leafPos = 0, leafEnd = 0;
-    float bestT = kFltMax, bestU = 0.0f, bestV = 0.0f;
-    int bestPrim = -1;
-
-    // Starts a BVH query for the ray (ro, rd).
-    auto beginQuery = [&]() {
-        inv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-        bestT = kFltMax;
-        bestPrim = -1;
-        sp = 0;
-        cur = P.rootRef;
-        leafPos = leafEnd = 0;
-        if (cur < 0) {
-            const unsigned bits = ~(unsigned)cur;
-            leafPos = bits >> 3;
-            leafEnd = leafPos + (bits & 7u) + 1u;
-        }
-        mode = kModeTrav;
-    };
+    bool hasExt = false;
 
     for (;;) {
         // ================================================================ shading phase
         if (mode == kModeShade) {
-            // one iteration of PathTrace's bounce loop (pathtracing.comp:25-140) around the
-            // closest-hit result (bestPrim, bestT, bestU, bestV) of the ray (ro, rd)
-            bool hasShadow = false;
-            hasExt = false;
+            if (q.bestPrim >= 0) nHits++;
+            const BounceRays br = shadeBounce(P, S, ps, q.ro, q.rd, q.bestPrim, q.bestT, q.bestU, q.bestV);
             mode = kModeFinish;
-            if (bestPrim < 0) {
-                float pdfLight = 0.0f;
-                v3 colorLight = evaluateHdri(S, P.envW, P.envH, P.hdriW, P.hdriH, rd, pdfLight);
-                float misWeight = 1.0f;
-                if (bounce > 0u) {
-                    float t = pdfBsdf * pdfBsdf;
-                    misWeight = t / (pdfLight * pdfLight + t);
-                }
-                if (misWeight > 0.0f) radiance = radiance + misWeight * throughput * colorLight * f / pdfBsdf;
-            } else {
-                nHits++;
-                // hit attributes of the winning triangle (intersection.glsl:41-57)
-                const float w = 1.0f - bestU - bestV;
-                const v3 P0 = ro + rd * bestT;
-                const float4* shp = reinterpret_cast<const float4*>(S.shading + bestPrim);
-                const float4 s0 = shp[0], s1 = shp[1], s2 = shp[2], s3 = shp[3], s4 = shp[4];
-                const float uvx = s0.w * w + s2.w * bestU + s3.y * bestV;
-                const float uvy = s1.w * w + s3.x * bestU + s3.z * bestV;
-                v3 N = normalize3(mk3(s0.x, s0.y, s0.z) * w + mk3(s1.x, s1.y, s1.z) * bestU + mk3(s2.x, s2.y, s2.z) * bestV);
-                const v3 Ng = mk3(s4.x, s4.y, s4.z);
-                const unsigned meshIndex = __float_as_uint(s3.w);
-                v3 tangent = splat(0.0f);
-                if (S.materials[meshIndex].tex[kTexNormal] >= 0) {
-                    const float4* tp = reinterpret_cast<const float4*>(S.triangles + bestPrim);
-                    const float4 q1 = tp[1], q2 = tp[2];
-                    const float dBx = s2.w - s0.w, dBy = s3.x - s1.w, dCx = s3.y - s0.w, dCy = s3.z - s1.w;
-                    const float invTd = 1.0f / (dBx * dCy - dBy * dCx);
-                    tangent = (mk3(q1.x, q1.y, q1.z) * dCy - mk3(q2.x, q2.y, q2.z) * dBy) * invTd;
-                }
-                const MaterialEval me = evaluateMaterial(S, P, meshIndex, uvx, uvy, N, tangent);
-                const v3 V = -rd;
-                const Surface surf = makeSurface(me, N, V);
-                radiance = radiance + throughput * surf.emission;
-                const v3 origin = offsetRay(P0, Ng);  // shared by the shadow and the extension ray (:66,:131)
-
-                // next-event estimation towards the HDRI (pathtracing.comp:64-102), everything
-                // but the occlusion test itself
-                const v3 Ll = sampleHdri(S, P.envW, P.envH, rng);
-                if (dot(N, Ll) > 0.0f) {
-                    hasShadow = true;
-                    pending = splat(0.0f);
-                    float pdfLight = 0.0f;
-                    v3 colorLight = evaluateHdri(S, P.envW, P.envH, P.hdriW, P.hdriH, Ll, pdfLight);
-                    const Dir dl = makeDir(surf, Ll);
-                    float pdfNee = 0.0f;
-                    const v3 fNee = evaluateBsdf(surf, dl, pdfNee);
-                    if (pdfNee > 0.0f) {
-                        float t = pdfLight * pdfLight;
-                        float misWeight = t / (pdfNee * pdfNee + t);
-                        if (misWeight > 0.0f) pending = misWeight * throughput * colorLight * fNee / pdfLight;
-                    }
-                }
-
-                // BSDF sampling, Russian roulette, next ray (pathtracing.comp:104-139)
-                const v3 L = sampleBsdf(surf, rng);
-                const Dir ds = makeDir(surf, L);
-                pdfBsdf = 0.0f;
-                f = evaluateBsdf(surf, ds, pdfBsdf);
-                if (!(pdfBsdf <= 0.0f)) {
-                    const float p = fmax_(throughput.x, fmax_(throughput.y, throughput.z));
-                    if (!(randomValue(rng) >= p)) {
-                        throughput = throughput * (1.0f / p);
-                        throughput = throughput * (f / pdfBsdf);
-                        if (bounce == 0u) {
-                            albedoRes = surf.albedo;
-                            normalRes = N;
-                        }
-                        bounce++;
-                        hasExt = bounce < P.maxBounces;
-                    }
-                }
-                // a shadow query whose pending contribution is exactly zero cannot change the
-                // result and is not issued (a NaN contribution still is)
-                hasShadow = hasShadow && !(pending.x == 0.0f && pending.y == 0.0f && pending.z == 0.0f);
-                if (hasShadow) {
-                    nShadow++;
-                    isShadow = true;
-                    extDir = L;
-                    ro = origin;
-                    rd = Ll;
-                    beginQuery();
-                } else if (hasExt) {
-                    nRays++;
-                    isShadow = false;
-                    hasExt = false;
-                    ro = origin;
-                    rd = L;
-                    beginQuery();
-                }
+            hasExt = false;
+            if (br.hasShadow) {
+                nShadow++;
+                pending = br.pending;
+                hasExt = br.hasExt;
+                extDir = br.extDir;
+                beginQuery(q, P.rootRef, br.origin, br.shadowDir, true);
+                mode = kModeTrav;
+            } else if (br.hasExt) {
+                nRays++;
+                beginQuery(q, P.rootRef, br.origin, br.extDir, false);
+                mode = kModeTrav;
             }
         }
         if (mode == kModeFinish) {
-            const float weight = 1.0f / (float)frame;
-            radianceImg[texel] = accumulate(radianceImg[texel], radiance, weight, P.accumulateMode);
-            albedoImg[texel] = accumulate(albedoImg[texel], albedoRes, weight, P.accumulateMode);
-            normalImg[texel] = accumulate(normalImg[texel], normalRes, weight, P.accumulateMode);
-            k++;
+            accumulateSample(P, img, texel, ps);
+            ps.k++;
             mode = kModeNew;
         }
         if (mode == kModeNew) {
-            if (k < kEnd) {
-                // main(): pathtracing.comp:206-245
-                frame = P.frameFirst + k * P.frameStride;
-                rng = pixelIndex + frame * 719393u;
-                float u = ((float)px + 0.5f) / P.frameW, v = ((float)py + 0.5f) / P.frameH;
-                if (P.antiAliasing != 0u) {
-                    float r1 = randomValue(rng);
-                    float r2 = randomValue(rng);
-                    u = u + (r1 - 0.5f) / P.frameW;
-                    v = v + (r2 - 0.5f) / P.frameH;
-                }
-                primaryRay(P, u, v, rng, ro, rd);
-                radiance = splat(0.0f);
-                throughput = splat(1.0f);
-                f = splat(1.0f);
-                pdfBsdf = 1.0f;
-                albedoRes = splat(0.0f);
-                normalRes = splat(0.0f);
-                bounce = 0;
-                isShadow = false;
+            if (ps.k < kEnd) {
+                v3 ro, rd;
+                startSample(P, px, py, ps, ro, rd);
                 hasExt = false;
                 nSamples++;
                 nRays++;
-                beginQuery();
+                beginQuery(q, P.rootRef, ro, rd, false);
+                mode = kModeTrav;
             } else {
                 mode = kModeDone;
             }
         }
-        const unsigned long long travMask = __ballot(mode == kModeTrav);
-        if (travMask == 0ull) break;
+        if (__ballot(mode == kModeTrav) == 0ull) break;
         // Leave the traversal phase once fewer than `threshold` lanes are traversing; lanes that
         // are done for good do not count against the wave.
         const int alive = __popcll(__ballot(mode != kModeDone));
@@ -298,97 +450,19 @@ __global__ __launch_bounds__(kBlockThreads, 4) void renderKernel(DevParams P, De
         // ============================================================== traversal phase
         for (;;) {
             if (mode == kModeTrav) {
-                bool finished = false;
-                // One 64-byte fetch per step, whichever record the lane needs: the current leaf's
-                // next triangle (48 B + 16 B of the following record) or the current interior node.
-                // Issuing it before the step diverges puts one memory round trip, not two, on the
-                // wave's critical path.
-                const bool atTriangle = leafPos < leafEnd;
-                const float4* rec = atTriangle ? reinterpret_cast<const float4*>(S.triangles + leafPos)
-                                               : reinterpret_cast<const float4*>(S.nodes + cur);
-                const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-                if (atTriangle) {
-                    // ---- one triangle of the current leaf: Moller-Trumbore with the shader's
-                    // expressions (intersection.glsl:26-40); edges and normal come precomputed
-                    if (COUNT) nTriTests++;
-                    const v3 n = mk3(r0.w, r1.w, r2.w);
-                    const v3 ab = mk3(r1.x, r1.y, r1.z), ac = mk3(r2.x, r2.y, r2.z);
-                    const v3 ao = ro - mk3(r0.x, r0.y, r0.z);
-                    const v3 dao = cross(ao, rd);
-                    const float det = -dot(rd, n);
-                    const float invDet = 1.0f / det;
-                    const float dst = dot(ao, n) * invDet;
-                    const float u = dot(ac, dao) * invDet;
-                    const float v = -dot(ab, dao) * invDet;
-                    const float w = 1.0f - u - v;
-                    const bool ok = det >= 1e-10f && dst >= 0.0f && u >= 0.0f && v >= 0.0f && w >= 0.0f;
-                    if (ok && (isShadow || dst < bestT)) {
-                        bestT = dst;
-                        bestU = u;
-                        bestV = v;
-                        bestPrim = (int)leafPos;
-                    }
-                    leafPos++;
-                    if (isShadow && ok) {
-                        finished = true;  // occluded
-                    } else if (leafPos == leafEnd) {
-                        if (sp == 0) {
-                            finished = true;
-                        } else {  // pop: the top entry is kept in a register
-                            cur = top;
-                            sp--;
-                            if (sp > 0) top = stack[(sp - 1) * kBlockThreads];
+                if (queryStep<COUNT>(S, q, stack, sc)) {
+                    if (q.isShadow) {
+                        if (q.bestPrim < 0) ps.radiance = ps.radiance + pending;  // unoccluded
+                        if (hasExt) {
+                            nRays++;
+                            hasExt = false;
+                            beginQuery(q, P.rootRef, q.ro, extDir, false);
+                        } else {
+                            mode = kModeFinish;
                         }
-                    }
-                } else {
-                    // ---- one interior node: both children's boxes from one 64-byte record
-                    if (COUNT) nNodeVisits++;
-                    float t0l, t0r;
-                    const float dl = hitAabb(ro, inv, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, t0l);
-                    const float dr = hitAabb(ro, inv, r2.x, r2.y, r2.z, r3.x, r3.y, r3.z, t0r);
-                    const float limit = bestT * kPruneMargin;  // bestT stays FLT_MAX for shadow rays
-                    const bool hl = dl > 0.0f && !(t0l > limit);
-                    const bool hr = dr > 0.0f && !(t0r > limit);
-                    const int left = __float_as_int(r0.w), right = __float_as_int(r1.w);
-                    if (hl && hr) {
-                        const bool leftFirst = dl < dr;  // intersection.glsl:169-180
-                        if (sp > 0) stack[(sp - 1) * kBlockThreads] = top;
-                        top = leftFirst ? right : left;
-                        sp++;
-                        if (COUNT) maxStack = (unsigned)sp > maxStack ? (unsigned)sp : maxStack;
-                        cur = leftFirst ? left : right;
-                    } else if (hl) {
-                        cur = left;
-                    } else if (hr) {
-                        cur = right;
-                    } else if (sp == 0) {
-                        finished = true;
                     } else {
-                        cur = top;
-                        sp--;
-                        if (sp > 0) top = stack[(sp - 1) * kBlockThreads];
+                        mode = kModeShade;
                     }
-                }
-                if (!finished) {
-                    if (cur < 0 && leafPos == leafEnd) {  // arrived at a leaf reference
-                        const unsigned bits = ~(unsigned)cur;
-                        leafPos = bits >> 3;
-                        leafEnd = leafPos + (bits & 7u) + 1u;
-                        cur = 0;
-                    }
-                } else if (isShadow) {
-                    if (bestPrim < 0) radiance = radiance + pending;  // unoccluded
-                    if (hasExt) {
-                        nRays++;
-                        isShadow = false;
-                        hasExt = false;
-                        rd = extDir;
-                        beginQuery();
-                    } else {
-                        mode = kModeFinish;
-                    }
-                } else {
-                    mode = kModeShade;
                 }
             }
             if (__popcll(__ballot(mode == kModeTrav)) < threshold) break;
@@ -396,10 +470,6 @@ __global__ __launch_bounds__(kBlockThreads, 4) void renderKernel(DevParams P, De
     }
 
     // counters: wave-level reduction, one atomic per wave and counter
-    auto waveSum = [](unsigned v) {
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        return v;
-    };
     const unsigned sRays = waveSum(nRays), sShadow = waveSum(nShadow), sHits = waveSum(nHits), sSamples = waveSum(nSamples);
     if (lane == 0) {
         atomicAdd(&counters->raysClosest, (unsigned long long)sRays);
@@ -408,17 +478,274 @@ __global__ __launch_bounds__(kBlockThreads, 4) void renderKernel(DevParams P, De
         atomicAdd(&counters->samples, (unsigned long long)sSamples);
     }
     if (COUNT) {
-        const unsigned sNodes = waveSum(nNodeVisits), sTris = waveSum(nTriTests);
-        unsigned m = maxStack;
-        for (int off = 32; off > 0; off >>= 1) {
-            unsigned o = __shfl_down(m, off, 64);
-            m = o > m ? o : m;
-        }
+        const unsigned sNodes = waveSum(sc.nodeVisits), sTris = waveSum(sc.triangleTests), m = waveMax(sc.maxStack);
         if (lane == 0) {
             atomicAdd(&counters->nodeVisits, (unsigned long long)sNodes);
             atomicAdd(&counters->triangleTests, (unsigned long long)sTris);
             atomicMax(&counters->maxStack, m);
         }
+    }
+}
+
+// ================================================================================= wavefront
+// Path state in global memory, one slot per pixel (slot = y * width + x).
+struct WfState {
+    float4* rayO;    // ray origin xyz (shared by a bounce's shadow and extension ray)
+    float4* rayD;    // extension ray direction xyz
+    float4* hit;     // closest hit: t, u, v, primitive index (int bits; -1 = miss)
+    float4* thrPdf;  // throughput xyz, pdfBsdf
+    float4* radRng;  // radiance xyz, rng state (uint bits)
+    float4* fMeta;   // f xyz, (bounce << 24 | sample index k) as uint bits
+    float4* shDir;   // shadow ray direction xyz
+    float4* pend;    // pending NEE contribution xyz
+    float4* aovA;    // primary albedo xyz
+    float4* aovN;    // primary normal xyz
+};
+
+// Ray queue entry: slot | flags.
+constexpr unsigned kEntryShadow = 0x80000000u;  // occlusion query along shDir (else extension along rayD)
+constexpr unsigned kEntryLast = 0x40000000u;    // shadow query that is the last ray of its path
+constexpr unsigned kEntrySlotMask = 0x3fffffffu;
+
+struct WfQueues {
+    const unsigned* rayIn;  // entries to trace this iteration
+    const unsigned* rayInCount;
+    unsigned* rayHead;    // next entry to hand out
+    unsigned* shadeQ;     // slots whose closest-hit query finished (traverseKernel appends)
+    unsigned* shadeCount;
+    unsigned* rayOut;     // next iteration's entries (shadeKernel appends)
+    unsigned* rayOutCount;
+};
+
+PT_DEV void loadPath(const DevParams& P, const WfState& W, unsigned slot, PathState& ps)
+{
+    const float4 a = W.thrPdf[slot], b = W.radRng[slot], c = W.fMeta[slot], d = W.aovA[slot], e = W.aovN[slot];
+    ps.throughput = mk3(a.x, a.y, a.z);
+    ps.pdfBsdf = a.w;
+    ps.radiance = mk3(b.x, b.y, b.z);
+    ps.rng = __float_as_uint(b.w);
+    ps.f = mk3(c.x, c.y, c.z);
+    const unsigned meta = __float_as_uint(c.w);
+    ps.bounce = meta >> 24;
+    ps.k = meta & 0x00ffffffu;
+    ps.frame = P.frameFirst + ps.k * P.frameStride;
+    ps.albedoRes = mk3(d.x, d.y, d.z);
+    ps.normalRes = mk3(e.x, e.y, e.z);
+}
+PT_DEV void storePath(const WfState& W, unsigned slot, const PathState& ps)
+{
+    W.thrPdf[slot] = make_float4(ps.throughput.x, ps.throughput.y, ps.throughput.z, ps.pdfBsdf);
+    W.radRng[slot] = make_float4(ps.radiance.x, ps.radiance.y, ps.radiance.z, __uint_as_float(ps.rng));
+    W.fMeta[slot] = make_float4(ps.f.x, ps.f.y, ps.f.z, __uint_as_float((ps.bounce << 24) | ps.k));
+    W.aovA[slot] = make_float4(ps.albedoRes.x, ps.albedoRes.y, ps.albedoRes.z, 0.0f);
+    W.aovN[slot] = make_float4(ps.normalRes.x, ps.normalRes.y, ps.normalRes.z, 0.0f);
+}
+
+// Appends `value` for every lane with `want` set: one atomic per wave, slots by prefix count.
+// Must be reached by all lanes of the wave that are still in the enclosing loop.
+PT_DEV void waveAppend(bool want, unsigned value, unsigned* queue, unsigned* count)
+{
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return;
+    const unsigned lane = threadIdx.x & 63u;
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned base = 0;
+    if ((int)lane == leader) base = atomicAdd(count, (unsigned)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (want) queue[base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = value;
+}
+
+// Accumulates the finished sample of `slot`, then starts the pixel's next sample if there is one.
+// Returns true with the primary ray in (ro, rd) and the fresh path state stored; false when the
+// pixel has no samples left.
+PT_DEV bool finishAndRestart(const DevParams& P, const WfState& W, const Images& img, unsigned slot, PathState& ps, v3& ro,
+                             v3& rd)
+{
+    accumulateSample(P, img, slot, ps);
+    ps.k++;
+    if (ps.k >= P.frameCount) return false;
+    const unsigned px = slot % P.width, py = slot / P.width;
+    startSample(P, px, py, ps, ro, rd);
+    storePath(W, slot, ps);
+    W.rayO[slot] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+    W.rayD[slot] = make_float4(rd.x, rd.y, rd.z, 0.0f);
+    return true;
+}
+
+// First sample of every pixel: path state, primary ray, one extension entry per pixel.
+__global__ __launch_bounds__(kBlockThreads) void wfStartKernel(DevParams P, WfState W, unsigned* rayOut,
+                                                              unsigned* rayOutCount, DevCounters* counters)
+{
+    const unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned total = P.width * P.height;
+    if (slot < total) {
+        PathState ps{};
+        ps.k = 0;
+        v3 ro, rd;
+        startSample(P, slot % P.width, slot / P.width, ps, ro, rd);
+        storePath(W, slot, ps);
+        W.rayO[slot] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+        W.rayD[slot] = make_float4(rd.x, rd.y, rd.z, 0.0f);
+        rayOut[slot] = slot;
+    }
+    if (slot == 0) {
+        *rayOutCount = total;
+        atomicAdd(&counters->samples, (unsigned long long)total);
+        atomicAdd(&counters->raysClosest, (unsigned long long)total);
+    }
+}
+
+template <int STACK, bool COUNT>
+__global__ __launch_bounds__(kBlockThreads) void traverseKernel(DevParams P, DevScene S, WfState W, Images img, WfQueues Q,
+                                                               DevCounters* counters)
+{
+    __shared__ int s_stack[STACK * kBlockThreads];
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    int* stack = s_stack + tid;
+    const unsigned total = *Q.rayInCount;
+
+    unsigned nRays = 0, nSamples = 0;
+    StepCounters sc{0u, 0u, 0u};
+    Query q{};
+    bool busy = false, exhausted = false;  // `exhausted` is wave-uniform
+    unsigned entry = 0;
+
+    for (;;) {
+        // ---- refill: idle lanes take the next queue entries (one atomic per wave)
+        const unsigned long long idle = __ballot(!busy);
+        const int nIdle = __popcll(idle);
+        if (!exhausted && (nIdle >= (int)P.refillMin || nIdle == 64)) {
+            const int leader = __ffsll((long long)idle) - 1;
+            unsigned base = 0;
+            if ((int)lane == leader) base = atomicAdd(Q.rayHead, (unsigned)nIdle);
+            base = __shfl(base, leader, 64);
+            if (base + (unsigned)nIdle >= total) exhausted = true;
+            if (!busy) {
+                const unsigned idx = base + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+                if (idx < total) {
+                    entry = Q.rayIn[idx];
+                    const unsigned slot = entry & kEntrySlotMask;
+                    const float4 o = W.rayO[slot];
+                    const bool shadow = (entry & kEntryShadow) != 0u;
+                    const float4 d = shadow ? W.shDir[slot] : W.rayD[slot];
+                    beginQuery(q, P.rootRef, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), shadow);
+                    busy = true;
+                }
+            }
+        }
+        if (__ballot(busy) == 0ull) break;  // nothing in flight: the refill above ran and found nothing
+
+        bool toShade = false;
+        unsigned shadeSlot = 0;
+        if (busy && queryStep<COUNT>(S, q, stack, sc)) {
+            const unsigned slot = entry & kEntrySlotMask;
+            busy = false;
+            if (q.isShadow) {
+                const bool last = (entry & kEntryLast) != 0u;
+                if (q.bestPrim < 0 || last) {
+                    float4 r = W.radRng[slot];
+                    if (q.bestPrim < 0) {  // unoccluded: the pending contribution counts
+                        const float4 pc = W.pend[slot];
+                        r.x = r.x + pc.x;
+                        r.y = r.y + pc.y;
+                        r.z = r.z + pc.z;
+                        if (!last) W.radRng[slot] = r;
+                    }
+                    if (last) {  // the path is over: accumulate, next sample, trace its primary ray here
+                        PathState ps;
+                        loadPath(P, W, slot, ps);
+                        ps.radiance = mk3(r.x, r.y, r.z);
+                        v3 ro, rd;
+                        if (finishAndRestart(P, W, img, slot, ps, ro, rd)) {
+                            nSamples++;
+                            nRays++;
+                            entry = slot;
+                            beginQuery(q, P.rootRef, ro, rd, false);
+                            busy = true;
+                        }
+                    }
+                }
+                // occluded and not last: nothing to do, the path goes on through its extension entry
+            } else {
+                W.hit[slot] = make_float4(q.bestT, q.bestU, q.bestV, __int_as_float(q.bestPrim));
+                toShade = true;
+                shadeSlot = slot;
+            }
+        }
+        waveAppend(toShade, shadeSlot, Q.shadeQ, Q.shadeCount);
+    }
+
+    const unsigned sRays = waveSum(nRays), sSamples = waveSum(nSamples);
+    if (lane == 0 && (sRays | sSamples)) {
+        atomicAdd(&counters->raysClosest, (unsigned long long)sRays);
+        atomicAdd(&counters->samples, (unsigned long long)sSamples);
+    }
+    if (COUNT) {
+        const unsigned sNodes = waveSum(sc.nodeVisits), sTris = waveSum(sc.triangleTests), m = waveMax(sc.maxStack);
+        if (lane == 0) {
+            atomicAdd(&counters->nodeVisits, (unsigned long long)sNodes);
+            atomicAdd(&counters->triangleTests, (unsigned long long)sTris);
+            atomicMax(&counters->maxStack, m);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlockThreads) void shadeKernel(DevParams P, DevScene S, WfState W, Images img, WfQueues Q,
+                                                            DevCounters* counters)
+{
+    const unsigned total = *Q.shadeCount;
+    const unsigned lane = threadIdx.x & 63u;
+    unsigned nRays = 0, nShadow = 0, nHits = 0, nSamples = 0;
+    // whole waves iterate together so the queue appends below see every lane
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned base = blockIdx.x * blockDim.x; base < total; base += stride) {
+        const unsigned idx = base + threadIdx.x;
+        unsigned e0 = 0, e1 = 0;
+        bool want0 = false, want1 = false;
+        if (idx < total) {
+            const unsigned slot = Q.shadeQ[idx];
+            PathState ps;
+            loadPath(P, W, slot, ps);
+            const float4 o = W.rayO[slot], d = W.rayD[slot], h = W.hit[slot];
+            const int prim = __float_as_int(h.w);
+            if (prim >= 0) nHits++;
+            const BounceRays br = shadeBounce(P, S, ps, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), prim, h.x, h.y, h.z);
+            if (br.hasShadow || br.hasExt) {
+                storePath(W, slot, ps);
+                W.rayO[slot] = make_float4(br.origin.x, br.origin.y, br.origin.z, 0.0f);
+                if (br.hasShadow) {
+                    W.shDir[slot] = make_float4(br.shadowDir.x, br.shadowDir.y, br.shadowDir.z, 0.0f);
+                    W.pend[slot] = make_float4(br.pending.x, br.pending.y, br.pending.z, 0.0f);
+                    e0 = slot | kEntryShadow | (br.hasExt ? 0u : kEntryLast);
+                    want0 = true;
+                    nShadow++;
+                }
+                if (br.hasExt) {
+                    W.rayD[slot] = make_float4(br.extDir.x, br.extDir.y, br.extDir.z, 0.0f);
+                    e1 = slot;
+                    want1 = true;
+                    nRays++;
+                }
+            } else {
+                v3 ro, rd;
+                if (finishAndRestart(P, W, img, slot, ps, ro, rd)) {
+                    e1 = slot;
+                    want1 = true;
+                    nRays++;
+                    nSamples++;
+                }
+            }
+        }
+        // shadow entries first: a path's shadow query then tends to run before its extension query
+        waveAppend(want0, e0, Q.rayOut, Q.rayOutCount);
+        waveAppend(want1, e1, Q.rayOut, Q.rayOutCount);
+    }
+    const unsigned sRays = waveSum(nRays), sShadow = waveSum(nShadow), sHits = waveSum(nHits), sSamples = waveSum(nSamples);
+    if (lane == 0 && (sRays | sShadow | sHits | sSamples)) {
+        atomicAdd(&counters->raysClosest, (unsigned long long)sRays);
+        atomicAdd(&counters->raysAny, (unsigned long long)sShadow);
+        atomicAdd(&counters->closestHits, (unsigned long long)sHits);
+        atomicAdd(&counters->samples, (unsigned long long)sSamples);
     }
 }
 

@@ -157,7 +157,8 @@ struct DevParams {
     int32_t envW, envH;
     int32_t rootRef;
     uint32_t tilesX, tilesY;
-    uint32_t travExitNum;  // leave the traversal phase below this many 64ths of the live lanes
+    uint32_t travExitNum;  // megakernel: leave the traversal phase below this many 64ths of the live lanes
+    uint32_t refillMin;    // wavefront: a wave refills from the ray queue once this many lanes are idle
 };
 
 struct DevCounters {

@@ -5,6 +5,7 @@
 // rendering path in this library: without a HIP device pt_create fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -101,6 +102,15 @@ struct pt_ctx {
     int32_t rootRef = 0;
     int maxDepth = 0;
     uint32_t travExitNum = 32;  // of 64
+    uint32_t refillMin = 16;
+    int pipeline = 0;    // 0 = wavefront, 1 = megakernel
+    int checkEvery = 2;  // wavefront: read the live-ray count back every this many iterations
+    int traverseBlocks = 0;
+    int lastIterations = 0;
+
+    // wavefront path state (one slot per pixel) and queues
+    DeviceBuffer dWfState[10], dRayQ[2], dShadeQ, dCtrl;
+    unsigned* hCtrl = nullptr;  // pinned mirror of one control word
     size_t nodeBytes = 0, triangleBytes = 0, shadingBytes = 0;
 };
 
@@ -207,6 +217,105 @@ int syncScene(pt_ctx* c)
     return PT_OK;
 }
 
+// Control words of the wavefront pipeline (device): ray counts and shade counts are double
+// buffered by iteration parity; each kernel zeroes the word the next kernel will append to.
+struct WfCtrl {
+    unsigned rayCount[2];
+    unsigned shadeCount[2];
+    unsigned rayHead;
+    unsigned pad[3];
+};
+
+__global__ void wfResetKernel(WfCtrl* ctrl)
+{
+    ctrl->rayCount[0] = ctrl->rayCount[1] = 0u;
+    ctrl->shadeCount[0] = ctrl->shadeCount[1] = 0u;
+    ctrl->rayHead = 0u;
+}
+
+// Zeroes the control words nobody uses during the current kernel, for the kernel after it.
+__global__ void wfPrepareKernel(unsigned* a, unsigned* b)
+{
+    if (a) *a = 0u;
+    if (b) *b = 0u;
+}
+
+int wavefrontDispatch(pt_ctx* c, const DevParams& P, const DevScene& S, const Images& img, DevCounters* ctr, bool counted)
+{
+    const size_t pixels = (size_t)c->width * c->height;
+    if (pixels > kEntrySlotMask) return fail(PT_ERR_INVALID, "image too large for the ray queue encoding");
+    if (P.frameCount > 0x00ffffffu) return fail(PT_ERR_INVALID, "more than 2^24 samples per pixel in one dispatch");
+    if (P.maxBounces > 255u) return fail(PT_ERR_INVALID, "the wavefront pipeline packs the bounce count into 8 bits");
+    for (DeviceBuffer& b : c->dWfState) HIP_TRY(b.ensure(pixels * sizeof(float4)));
+    HIP_TRY(c->dRayQ[0].ensure(2 * pixels * sizeof(unsigned)));
+    HIP_TRY(c->dRayQ[1].ensure(2 * pixels * sizeof(unsigned)));
+    HIP_TRY(c->dShadeQ.ensure(pixels * sizeof(unsigned)));
+    HIP_TRY(c->dCtrl.ensure(sizeof(WfCtrl)));
+    if (!c->hCtrl) HIP_TRY(hipHostMalloc((void**)&c->hCtrl, 64));
+    if (c->traverseBlocks == 0) {
+        int perCu = 0;
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, traverseKernel<32, false>, kBlockThreads, 0));
+        if (perCu < 1) perCu = 1;
+        c->traverseBlocks = perCu * prop.multiProcessorCount;
+    }
+    WfState W{};
+    float4** fields[10] = {&W.rayO, &W.rayD, &W.hit, &W.thrPdf, &W.radRng, &W.fMeta, &W.shDir, &W.pend, &W.aovA, &W.aovN};
+    for (int i = 0; i < 10; i++) *fields[i] = (float4*)c->dWfState[i].ptr;
+    WfCtrl* ctrl = (WfCtrl*)c->dCtrl.ptr;
+    unsigned* rayQ[2] = {(unsigned*)c->dRayQ[0].ptr, (unsigned*)c->dRayQ[1].ptr};
+    const dim3 block(kBlockThreads);
+    const bool deep = c->maxDepth > 32;
+
+    hipLaunchKernelGGL(wfResetKernel, dim3(1), dim3(1), 0, c->stream, ctrl);
+    hipLaunchKernelGGL(wfStartKernel, dim3((unsigned)((pixels + kBlockThreads - 1) / kBlockThreads)), block, 0, c->stream, P, W,
+                       rayQ[0], &ctrl->rayCount[0], ctr);
+    HIP_TRY(hipGetLastError());
+    const unsigned shadeBlocks = (unsigned)std::min<size_t>((pixels + kBlockThreads - 1) / kBlockThreads, 4096);
+    // every pixel shades at most max_bounces times per sample, plus the pass that ends its last sample
+    const uint64_t maxIter = (uint64_t)P.frameCount * P.maxBounces + 2;
+    int iter = 0;
+    for (uint64_t i = 0; i < maxIter; i++, iter++) {
+        const int cur = (int)(i & 1u), nxt = cur ^ 1;
+        WfQueues Q{};
+        Q.rayIn = rayQ[cur];
+        Q.rayInCount = &ctrl->rayCount[cur];
+        Q.rayHead = &ctrl->rayHead;
+        Q.shadeQ = (unsigned*)c->dShadeQ.ptr;
+        Q.shadeCount = &ctrl->shadeCount[cur];
+        Q.rayOut = rayQ[nxt];
+        Q.rayOutCount = &ctrl->rayCount[nxt];
+        const dim3 tgrid((unsigned)c->traverseBlocks);
+        if (counted) {
+            if (deep)
+                hipLaunchKernelGGL((traverseKernel<64, true>), tgrid, block, 0, c->stream, P, S, W, img, Q, ctr);
+            else
+                hipLaunchKernelGGL((traverseKernel<32, true>), tgrid, block, 0, c->stream, P, S, W, img, Q, ctr);
+        } else {
+            if (deep)
+                hipLaunchKernelGGL((traverseKernel<64, false>), tgrid, block, 0, c->stream, P, S, W, img, Q, ctr);
+            else
+                hipLaunchKernelGGL((traverseKernel<32, false>), tgrid, block, 0, c->stream, P, S, W, img, Q, ctr);
+        }
+        // the ray head and the other parity's words are idle now: zero them for the next users
+        hipLaunchKernelGGL(wfPrepareKernel, dim3(1), dim3(1), 0, c->stream, &ctrl->rayCount[nxt], (unsigned*)nullptr);
+        hipLaunchKernelGGL(shadeKernel, dim3(shadeBlocks), block, 0, c->stream, P, S, W, img, Q, ctr);
+        hipLaunchKernelGGL(wfPrepareKernel, dim3(1), dim3(1), 0, c->stream, &ctrl->rayHead, &ctrl->shadeCount[nxt]);
+        HIP_TRY(hipGetLastError());
+        if ((i + 1) % (uint64_t)c->checkEvery == 0) {
+            HIP_TRY(hipMemcpyAsync(c->hCtrl, &ctrl->rayCount[nxt], sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (*c->hCtrl == 0u) {
+                iter++;
+                break;
+            }
+        }
+    }
+    c->lastIterations = iter;
+    return PT_OK;
+}
+
 int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t frameStride, bool counted)
 {
     if (!c) return fail(PT_ERR_INVALID, "null context");
@@ -248,7 +357,6 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
     P.rootRef = c->rootRef;
     P.tilesX = (uint32_t)((c->width + 15) / 16);
     P.tilesY = (uint32_t)((c->height + 15) / 16);
-    P.travExitNum = c->travExitNum;
 
     DevScene S{};
     S.nodes = (const DevNode*)c->dNodes.ptr;
@@ -261,24 +369,32 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
     S.envColorPdf = (const float4*)c->dEnvColorPdf.ptr;
     S.envSample = (const float2*)c->dEnvSample.ptr;
 
+    P.travExitNum = c->travExitNum;
+    P.refillMin = c->refillMin;
     HIP_TRY(hipMemsetAsync(c->dCounters.ptr, 0, sizeof(DevCounters), c->stream));
-    const dim3 grid(P.tilesX * P.tilesY), block(kBlockThreads);
+    const dim3 block(kBlockThreads);
     DevCounters* ctr = (DevCounters*)c->dCounters.ptr;
-    float4 *i0 = imagePtr(c, 0), *i1 = imagePtr(c, 1), *i2 = imagePtr(c, 2);
-    HIP_TRY(hipEventRecord(c->evStart, c->stream));
+    Images img{imagePtr(c, 0), imagePtr(c, 1), imagePtr(c, 2)};
     const bool deep = c->maxDepth > 32;
-    if (counted) {
-        if (deep)
-            hipLaunchKernelGGL((renderKernel<64, true>), grid, block, 0, c->stream, P, S, i0, i1, i2, ctr);
-        else
-            hipLaunchKernelGGL((renderKernel<32, true>), grid, block, 0, c->stream, P, S, i0, i1, i2, ctr);
+    HIP_TRY(hipEventRecord(c->evStart, c->stream));
+    if (c->pipeline == 1) {
+        const dim3 grid(P.tilesX * P.tilesY);
+        if (counted) {
+            if (deep)
+                hipLaunchKernelGGL((renderKernel<64, true>), grid, block, 0, c->stream, P, S, img, ctr);
+            else
+                hipLaunchKernelGGL((renderKernel<32, true>), grid, block, 0, c->stream, P, S, img, ctr);
+        } else {
+            if (deep)
+                hipLaunchKernelGGL((renderKernel<64, false>), grid, block, 0, c->stream, P, S, img, ctr);
+            else
+                hipLaunchKernelGGL((renderKernel<32, false>), grid, block, 0, c->stream, P, S, img, ctr);
+        }
+        HIP_TRY(hipGetLastError());
     } else {
-        if (deep)
-            hipLaunchKernelGGL((renderKernel<64, false>), grid, block, 0, c->stream, P, S, i0, i1, i2, ctr);
-        else
-            hipLaunchKernelGGL((renderKernel<32, false>), grid, block, 0, c->stream, P, S, i0, i1, i2, ctr);
+        int rc2 = wavefrontDispatch(c, P, S, img, ctr, counted);
+        if (rc2 != PT_OK) return rc2;
     }
-    HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->evStop, c->stream));
     c->timed = true;
     return PT_OK;
@@ -337,6 +453,12 @@ void pt_destroy(pt_ctx* c)
                            &c->dSrgbLut, &c->dEnvColorPdf, &c->dEnvSample, &c->dImages[0], &c->dImages[1],
                            &c->dImages[2], &c->dCounters};
     for (DeviceBuffer* b : all) b->release();
+    for (DeviceBuffer& b : c->dWfState) b.release();
+    c->dRayQ[0].release();
+    c->dRayQ[1].release();
+    c->dShadeQ.release();
+    c->dCtrl.release();
+    if (c->hCtrl) (void)hipHostFree(c->hCtrl);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
@@ -686,13 +808,35 @@ int pt_scene_bytes(pt_ctx* c, uint64_t* nodeBytes, uint64_t* triangleBytes, uint
     return PT_OK;
 }
 
-// Tuning hook: share of live lanes (in 64ths) below which a wave leaves its traversal phase.
-int pt_debug_set_tuning(pt_ctx* c, int travExit64ths)
+// Tuning hook.  key 0: pipeline (0 wavefront, 1 megakernel); 1: megakernel traversal-phase exit
+// threshold in 64ths of the live lanes; 2: wavefront refill threshold (idle lanes); 3: wavefront
+// iterations between read-backs of the live-ray count; 4: traverse grid size in blocks (0 = auto).
+int pt_debug_set_tuning(pt_ctx* c, int key, int value)
 {
     if (!c) return fail(PT_ERR_INVALID, "null context");
-    if (travExit64ths < 1 || travExit64ths > 64) return fail(PT_ERR_INVALID, "threshold must be 1..64");
-    c->travExitNum = (uint32_t)travExit64ths;
-    return PT_OK;
+    switch (key) {
+    case 0:
+        if (value != 0 && value != 1) return fail(PT_ERR_INVALID, "pipeline must be 0 or 1");
+        c->pipeline = value;
+        return PT_OK;
+    case 1:
+        if (value < 1 || value > 64) return fail(PT_ERR_INVALID, "threshold must be 1..64");
+        c->travExitNum = (uint32_t)value;
+        return PT_OK;
+    case 2:
+        if (value < 1 || value > 64) return fail(PT_ERR_INVALID, "refill threshold must be 1..64");
+        c->refillMin = (uint32_t)value;
+        return PT_OK;
+    case 3:
+        if (value < 1) return fail(PT_ERR_INVALID, "check interval must be >= 1");
+        c->checkEvery = value;
+        return PT_OK;
+    case 4:
+        if (value < 0 || value > 65535) return fail(PT_ERR_INVALID, "bad grid size");
+        c->traverseBlocks = value;
+        return PT_OK;
+    default: return fail(PT_ERR_INVALID, "unknown tuning key");
+    }
 }
 
 // Test hook (not part of the drop-in surface): evaluates one float32 building block of the

@@ -106,8 +106,12 @@ class Renderer:
         fn = self._lib.pt_dispatch_counted if counted else self._lib.pt_dispatch
         check(fn(self._h, int(frame_first), int(frame_count), int(frame_stride)))
 
-    def set_tuning(self, trav_exit_64ths):
-        check(self._lib.pt_debug_set_tuning(self._h, int(trav_exit_64ths)))
+    TUNING_KEYS = {"pipeline": 0, "trav_exit": 1, "refill_min": 2, "check_every": 3, "traverse_blocks": 4}
+
+    def set_tuning(self, **kw):
+        """pipeline=0|1 (wavefront|megakernel), trav_exit, refill_min, check_every, traverse_blocks."""
+        for k, v in kw.items():
+            check(self._lib.pt_debug_set_tuning(self._h, self.TUNING_KEYS[k], int(v)))
 
     def scale_images(self, scale):
         check(self._lib.pt_scale_images(self._h, float(scale)))

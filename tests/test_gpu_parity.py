@@ -20,15 +20,18 @@ from tests.common import built_scene, environment
 pytestmark = pytest.mark.gpu
 
 MAX_DIFF_FRACTION = 1e-4
+# both schedulers drive the same device code and must give the same bits
+PIPELINES = pytest.mark.parametrize("pipeline", [0, 1], ids=["wavefront", "megakernel"])
 
 
-def _pair(recipe, width, height, env=(256, 128), textures=None):
+def _pair(recipe, width, height, env=(256, 128), textures=None, pipeline=0):
     nodes, prims, mats = built_scene(recipe) if isinstance(recipe, str) else recipe
     hdri, cache = environment(*env)
     o = ob.Oracle()
     o.set_scene(nodes, prims, mats)
     o.set_environment(hdri, cache)
     g = R.Renderer(width, height)
+    g.set_tuning(pipeline=pipeline)
     g.upload_nodes(nodes)
     g.upload_primitives(prims)
     g.upload_materials(mats)
@@ -103,8 +106,9 @@ def test_math_building_blocks_bit_exact(fn, name):
     assert bad.size == 0, f"{name}: {bad.size} mismatches, first a={a[bad[0]]!r} b={b[bad[0]]!r} gpu={gpu[bad[0]]!r} cpu={cpu[bad[0]]!r}"
 
 
-def test_small_scene_all_lobes_bit_exact():
-    o, g = _pair("TorusMixed", 96, 80)
+@PIPELINES
+def test_small_scene_all_lobes_bit_exact(pipeline):
+    o, g = _pair("TorusMixed", 96, 80, pipeline=pipeline)
     p = R.default_params(96, 80)
     g.set_params(p)
     g.clear()
@@ -122,9 +126,10 @@ def test_small_scene_all_lobes_bit_exact():
     assert np.isfinite(gpu[0]).all() and gpu[0][..., :3].mean() > 0.01
 
 
+@PIPELINES
 @pytest.mark.parametrize("recipe", ["BunnyClearcoat", "BunnyGlass", "BunnyDielectric", "BunnyMetallic"])
-def test_bunny_recipes_one_spp_bit_exact(recipe):
-    o, g = _pair(recipe, 256, 256)
+def test_bunny_recipes_one_spp_bit_exact(recipe, pipeline):
+    o, g = _pair(recipe, 256, 256, pipeline=pipeline)
     p = R.default_params(256, 256)
     g.set_params(p)
     g.clear()
@@ -134,9 +139,10 @@ def test_bunny_recipes_one_spp_bit_exact(recipe):
     _assert_images_equal(gpu, cpu[:3], cpu[3], f"{recipe} 256x256 1spp")
 
 
-def test_c1_bunny_clearcoat_512_first_and_later_frames():
+@PIPELINES
+def test_c1_bunny_clearcoat_512_first_and_later_frames(pipeline):
     # BASELINE configs[0]: BunnyClearcoat 512x512, fixed seed pixelIndex + FrameCount*719393
-    o, g = _pair("BunnyClearcoat", 512, 512, env=(1024, 512))
+    o, g = _pair("BunnyClearcoat", 512, 512, env=(1024, 512), pipeline=pipeline)
     p = R.default_params(512, 512)
     g.set_params(p)
     g.clear()
@@ -151,8 +157,9 @@ def test_c1_bunny_clearcoat_512_first_and_later_frames():
     _assert_images_equal(gpu, cpu2[:3], cpu[3] | cpu2[3], "C1 frames 1-4")
 
 
-def test_deep_paths_eight_bounces():
-    o, g = _pair("BunnyGlass", 192, 160)
+@PIPELINES
+def test_deep_paths_eight_bounces(pipeline):
+    o, g = _pair("BunnyGlass", 192, 160, pipeline=pipeline)
     p = R.default_params(192, 160)
     p.max_bounces = 8
     g.set_params(p)
@@ -163,8 +170,9 @@ def test_deep_paths_eight_bounces():
     _assert_images_equal(gpu, cpu[:3], cpu[3], "BunnyGlass 8 bounces")
 
 
-def test_thin_lens_no_antialiasing_and_modifiers():
-    o, g = _pair("TorusMixed", 64, 64)
+@PIPELINES
+def test_thin_lens_no_antialiasing_and_modifiers(pipeline):
+    o, g = _pair("TorusMixed", 64, 64, pipeline=pipeline)
     p = R.default_params(64, 64)
     p.aperture_size = 0.08
     p.aperture_shape[0], p.aperture_shape[1] = 1.0, 0.5
@@ -182,9 +190,10 @@ def test_thin_lens_no_antialiasing_and_modifiers():
     _assert_images_equal(gpu, cpu[:3], cpu[3], "thin lens")
 
 
-def test_ragged_image_size_renders_every_row():
+@PIPELINES
+def test_ragged_image_size_renders_every_row(pipeline):
     # 100 x 70 is not a multiple of the 16x16 tile; the reference would drop rows 64..69
-    o, g = _pair("TorusMixed", 100, 70)
+    o, g = _pair("TorusMixed", 100, 70, pipeline=pipeline)
     p = R.default_params(100, 70)
     g.set_params(p)
     g.clear()
@@ -195,8 +204,9 @@ def test_ragged_image_size_renders_every_row():
     assert np.all(gpu[0][..., 3] == 1.0)
 
 
-def test_multi_frame_launch_equals_frame_by_frame():
-    _, g = _pair("TorusMixed", 64, 48)
+@PIPELINES
+def test_multi_frame_launch_equals_frame_by_frame(pipeline):
+    _, g = _pair("TorusMixed", 64, 48, pipeline=pipeline)
     p = R.default_params(64, 48)
     g.set_params(p)
     g.clear()
@@ -210,8 +220,9 @@ def test_multi_frame_launch_equals_frame_by_frame():
         assert a.tobytes() == b.tobytes()
 
 
-def test_sum_mode_and_scale():
-    o, g = _pair("TorusMixed", 64, 48)
+@PIPELINES
+def test_sum_mode_and_scale(pipeline):
+    o, g = _pair("TorusMixed", 64, 48, pipeline=pipeline)
     p = R.default_params(64, 48)
     p.accumulate_mode = 1
     g.set_params(p)
@@ -253,9 +264,10 @@ def _textured_quad_scene():
     return (R.align_nodes(nodes), R.align_primitives(sp), mats), tex
 
 
-def test_textured_materials_bit_exact():
+@PIPELINES
+def test_textured_materials_bit_exact(pipeline):
     scene, tex = _textured_quad_scene()
-    o, g = _pair(scene, 80, 80, textures=tex)
+    o, g = _pair(scene, 80, 80, textures=tex, pipeline=pipeline)
     p = R.default_params(80, 80)
     g.set_params(p)
     g.clear()
