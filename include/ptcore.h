@@ -214,7 +214,7 @@ int pt_last_dispatch_ms(pt_ctx* ctx, float* ms_out);
 int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, uint64_t* shading_bytes);
 
 /* Tuning hook, not part of the drop-in surface (no counterpart in the reference).  key 0: scheduler
- * (0 = wavefront pipeline, the default; 1 = single-launch megakernel); 1: megakernel traversal-phase
+ * (0 = single-launch megakernel, the default; 1 = wavefront pipeline); 1: megakernel traversal-phase
  * exit threshold in 64ths of the live lanes (default 32); 2: wavefront refill threshold in idle
  * lanes (default 16); 3: wavefront iterations between read-backs of the live-ray count (default 2);
  * 4: traverse grid size in blocks (0 = sized from the occupancy query). */

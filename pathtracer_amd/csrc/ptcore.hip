@@ -103,7 +103,7 @@ struct pt_ctx {
     int maxDepth = 0;
     uint32_t travExitNum = 32;  // of 64
     uint32_t refillMin = 16;
-    int pipeline = 0;    // 0 = wavefront, 1 = megakernel
+    int pipeline = 0;    // 0 = megakernel, 1 = wavefront
     int checkEvery = 2;  // wavefront: read the live-ray count back every this many iterations
     int traverseBlocks = 0;
     int lastIterations = 0;
@@ -377,7 +377,7 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
     Images img{imagePtr(c, 0), imagePtr(c, 1), imagePtr(c, 2)};
     const bool deep = c->maxDepth > 32;
     HIP_TRY(hipEventRecord(c->evStart, c->stream));
-    if (c->pipeline == 1) {
+    if (c->pipeline == 0) {
         const dim3 grid(P.tilesX * P.tilesY);
         if (counted) {
             if (deep)
@@ -808,7 +808,7 @@ int pt_scene_bytes(pt_ctx* c, uint64_t* nodeBytes, uint64_t* triangleBytes, uint
     return PT_OK;
 }
 
-// Tuning hook.  key 0: pipeline (0 wavefront, 1 megakernel); 1: megakernel traversal-phase exit
+// Tuning hook.  key 0: pipeline (0 megakernel, 1 wavefront); 1: megakernel traversal-phase exit
 // threshold in 64ths of the live lanes; 2: wavefront refill threshold (idle lanes); 3: wavefront
 // iterations between read-backs of the live-ray count; 4: traverse grid size in blocks (0 = auto).
 int pt_debug_set_tuning(pt_ctx* c, int key, int value)

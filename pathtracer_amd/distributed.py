@@ -14,6 +14,21 @@ import torch
 from . import renderer as R
 
 
+def shard_frames(rank, world, total_spp, first_frame=1):
+    """(first FrameCount, count, stride) of rank `rank` when `total_spp` consecutive FrameCount
+    values starting at `first_frame` are dealt round-robin to `world` ranks."""
+    count = (total_spp - rank + world - 1) // world if total_spp > rank else 0
+    return first_frame + rank, count, world
+
+
+def reduce_sum(images, group=None):
+    """In-place sum over ranks of a stacked accumulation tensor (the path's only collective)."""
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(images, op=dist.ReduceOp.SUM, group=group)
+    return images
+
+
 class ShardedRenderer:
     def __init__(self, width, height, device_index, rank=0, world=1):
         self.rank, self.world = int(rank), int(world)
@@ -57,10 +72,9 @@ class ShardedRenderer:
         three images); this rank's own sums stay intact so rendering can continue.  A no-op on one
         GPU, where `total` aliases `images`."""
         if self.world > 1:
-            import torch.distributed as dist
             with torch.cuda.stream(self.stream):
                 self.total.copy_(self.images)
-                dist.all_reduce(self.total, op=dist.ReduceOp.SUM)
+                reduce_sum(self.total)
 
     def resolve(self, total_samples):
         """Mean images after reduce(): the summed buffers divided by the global sample count."""

@@ -109,7 +109,7 @@ class Renderer:
     TUNING_KEYS = {"pipeline": 0, "trav_exit": 1, "refill_min": 2, "check_every": 3, "traverse_blocks": 4}
 
     def set_tuning(self, **kw):
-        """pipeline=0|1 (wavefront|megakernel), trav_exit, refill_min, check_every, traverse_blocks."""
+        """pipeline=0|1 (megakernel|wavefront), trav_exit, refill_min, check_every, traverse_blocks."""
         for k, v in kw.items():
             check(self._lib.pt_debug_set_tuning(self._h, self.TUNING_KEYS[k], int(v)))
 

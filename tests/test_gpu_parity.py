@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 
 MAX_DIFF_FRACTION = 1e-4
 # both schedulers drive the same device code and must give the same bits
-PIPELINES = pytest.mark.parametrize("pipeline", [0, 1], ids=["wavefront", "megakernel"])
+PIPELINES = pytest.mark.parametrize("pipeline", [0, 1], ids=["megakernel", "wavefront"])
 
 
 def _pair(recipe, width, height, env=(256, 128), textures=None, pipeline=0):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""In-process A/B sweep of the traversal-phase exit threshold on the benchmark workload.
-    python tools/sweep.py [--spp 16] [--rounds 3] 8 16 24 32 40 48 56 64
+"""In-process A/B of scheduler settings on the benchmark workload (interleaved rounds).
+    python tools/sweep.py --spp 16 --rounds 3 pipeline=0 pipeline=1 pipeline=0,refill_min=32
+Each positional argument is one variant: comma-separated key=value tuning settings.
 """
 import argparse
 import os
@@ -13,11 +14,13 @@ import bench  # noqa: E402
 from pathtracer_amd import renderer as R  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("values", nargs="*", type=int, default=[16, 24, 32, 40, 48, 56])
+ap.add_argument("variants", nargs="*", default=["pipeline=0", "pipeline=1"])
 ap.add_argument("--spp", type=int, default=16)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--bounces", type=int, default=8)
 ap.add_argument("--subdivide", type=int, default=0)
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
 a = ap.parse_args()
 
 
@@ -26,23 +29,35 @@ class A:
 
 
 work = bench.build_workload(A)
-g = R.Renderer(1920, 1080)
+g = R.Renderer(a.width, a.height)
 g.upload_nodes(work["nodes"]); g.upload_primitives(work["prims"]); g.upload_materials(work["mats"])
 g.upload_environment(work["hdri"], work["cache"])
-p = R.default_params(1920, 1080)
+p = R.default_params(a.width, a.height)
 p.max_bounces = a.bounces
 g.set_params(p)
-g.dispatch(1, 2, 1); g.synchronize()
-res = {v: [] for v in a.values}
+defaults = dict(pipeline=0, trav_exit=32, refill_min=16, check_every=2, traverse_blocks=0)
+variants = []
+for v in a.variants:
+    kw = dict(defaults)
+    for item in v.split(","):
+        k, val = item.split("=")
+        kw[k] = int(val)
+    variants.append((v, kw))
+for _, kw in variants:  # warm every kernel
+    g.set_tuning(**kw)
+    g.dispatch(1, 1, 1)
+g.synchronize()
+res = {v: [] for v, _ in variants}
+rays = {}
 for r in range(a.rounds):
-    for v in a.values:
-        g.set_tuning(v)
+    for v, kw in variants:
+        g.set_tuning(**kw)
         g.clear()
         g.dispatch(1, a.spp, 1)
         g.synchronize()
         res[v].append(g.last_dispatch_ms())
-st = g.stats()
-rays = st.rays_closest + st.rays_any
-for v in a.values:
+        st = g.stats()
+        rays[v] = st.rays_closest + st.rays_any
+for v, _ in variants:
     ms = np.array(res[v])
-    print(f"trav_exit={v:3d}/64  median {np.median(ms):8.3f} ms  min {ms.min():8.3f} ms  -> {rays / np.median(ms) / 1e3:8.1f} Mrays/s")
+    print(f"{v:44s} median {np.median(ms):8.3f} ms  min {ms.min():8.3f} ms  -> {rays[v] / np.median(ms) / 1e3:8.1f} Mrays/s")
