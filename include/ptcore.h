@@ -220,6 +220,14 @@ int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, 
  * 4: traverse grid size in blocks (0 = sized from the occupancy query). */
 int pt_debug_set_tuning(pt_ctx* ctx, int key, int value);
 
+/* Profiling hook, not part of the drop-in surface (no counterpart in the reference): wave-level
+ * occupancy counters of the most recent pt_dispatch_counted() under the megakernel scheduler:
+ * [0] traversal iterations, [1] lanes traversing in them, [2] iterations with a node step, [3] lanes
+ * in node steps, [4] iterations with a triangle step, [5] lanes in triangle steps, [6] shading phases
+ * that shaded something, [7] lanes shading a hit, [8] lanes shading a miss, [9] shading phases,
+ * [10] lanes finishing a sample, [11] lanes starting a sample. */
+int pt_debug_get_profile(pt_ctx* ctx, uint64_t out12[12]);
+
 /* Test hook, not part of the drop-in surface (no counterpart in the reference): evaluates one
  * float32 building block of the kernels element-wise on the device so that tests can compare it
  * bit for bit with a CPU evaluation of the same operation sequence.  fn: 0 sin, 1 cos, 2 asin,

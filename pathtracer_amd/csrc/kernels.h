@@ -102,7 +102,6 @@ PT_DEV void beginQuery(Query& q, int rootRef, v3 ro, v3 rd, bool isShadow)
 template <bool COUNT>
 PT_DEV bool queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc)
 {
-    bool finished = false;
     // One 64-byte fetch per step, whichever record the lane needs: the current leaf's next
     // triangle (48 B + 16 B of the following record) or the current interior node.  Issuing it
     // before the step diverges puts one memory round trip, not two, on the wave's critical path.
@@ -110,6 +109,8 @@ PT_DEV bool queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc)
     const float4* rec = atTriangle ? reinterpret_cast<const float4*>(S.triangles + q.leafPos)
                                    : reinterpret_cast<const float4*>(S.nodes + q.cur);
     const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+    bool finished = false;  // query complete
+    bool pop = false;       // this step ends with taking the next sub-tree off the stack
     if (atTriangle) {
         // Moller-Trumbore with the shader's expressions (intersection.glsl:26-40); the edges and
         // their cross product come precomputed from the host.
@@ -125,24 +126,14 @@ PT_DEV bool queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc)
         const float v = -dot(ab, dao) * invDet;
         const float w = 1.0f - u - v;
         const bool ok = det >= 1e-10f && dst >= 0.0f && u >= 0.0f && v >= 0.0f && w >= 0.0f;
-        if (ok && (q.isShadow || dst < q.bestT)) {
-            q.bestT = dst;
-            q.bestU = u;
-            q.bestV = v;
-            q.bestPrim = (int)q.leafPos;
-        }
+        const bool better = ok && (q.isShadow || dst < q.bestT);
+        q.bestT = better ? dst : q.bestT;
+        q.bestU = better ? u : q.bestU;
+        q.bestV = better ? v : q.bestV;
+        q.bestPrim = better ? (int)q.leafPos : q.bestPrim;
         q.leafPos++;
-        if (q.isShadow && ok) {
-            finished = true;  // occluded
-        } else if (q.leafPos == q.leafEnd) {
-            if (q.sp == 0) {
-                finished = true;
-            } else {
-                q.cur = q.top;
-                q.sp--;
-                if (q.sp > 0) q.top = stack[(q.sp - 1) * kBlockThreads];
-            }
-        }
+        finished = q.isShadow && ok;  // occluded
+        pop = !finished && q.leafPos == q.leafEnd;
     } else {
         if (COUNT) sc.nodeVisits++;
         float t0l, t0r;
@@ -152,24 +143,22 @@ PT_DEV bool queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc)
         const bool hl = dl > 0.0f && !(t0l > limit);
         const bool hr = dr > 0.0f && !(t0r > limit);
         const int left = __float_as_int(r0.w), right = __float_as_int(r1.w);
-        if (hl && hr) {
-            const bool leftFirst = dl < dr;  // intersection.glsl:169-180
+        const bool both = hl && hr;
+        const bool leftFirst = dl < dr;  // intersection.glsl:169-180
+        if (both) {  // postpone the far child
             if (q.sp > 0) stack[(q.sp - 1) * kBlockThreads] = q.top;
             q.top = leftFirst ? right : left;
             q.sp++;
             if (COUNT) sc.maxStack = (unsigned)q.sp > sc.maxStack ? (unsigned)q.sp : sc.maxStack;
-            q.cur = leftFirst ? left : right;
-        } else if (hl) {
-            q.cur = left;
-        } else if (hr) {
-            q.cur = right;
-        } else if (q.sp == 0) {
-            finished = true;
-        } else {
-            q.cur = q.top;
-            q.sp--;
-            if (q.sp > 0) q.top = stack[(q.sp - 1) * kBlockThreads];
         }
+        q.cur = both ? (leftFirst ? left : right) : (hl ? left : right);
+        pop = !(hl || hr);
+    }
+    if (pop) {
+        finished = q.sp == 0;
+        q.cur = q.top;
+        q.sp = finished ? 0 : q.sp - 1;
+        if (q.sp > 0) q.top = stack[(q.sp - 1) * kBlockThreads];
     }
     if (!finished && q.cur < 0 && q.leafPos == q.leafEnd) {  // arrived at a leaf reference
         const unsigned bits = ~(unsigned)q.cur;
@@ -403,8 +392,16 @@ __global__ __launch_bounds__(kBlockThreads, 4) void renderKernel(DevParams P, De
     v3 pending = splat(0.0f);  // NEE contribution, added if the shadow ray is unoccluded
     bool hasExt = false;
 
+    unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // wave-uniform, counting build only
     for (;;) {
         // ================================================================ shading phase
+        if (COUNT) {
+            const int nShade = __popcll(__ballot(mode == kModeShade));
+            prof[9]++;
+            if (nShade) prof[6]++;
+            prof[7] += (unsigned)__popcll(__ballot(mode == kModeShade && q.bestPrim >= 0));
+            prof[8] += (unsigned)__popcll(__ballot(mode == kModeShade && q.bestPrim < 0));
+        }
         if (mode == kModeShade) {
             if (q.bestPrim >= 0) nHits++;
             const BounceRays br = shadeBounce(P, S, ps, q.ro, q.rd, q.bestPrim, q.bestT, q.bestU, q.bestV);
@@ -423,11 +420,13 @@ __global__ __launch_bounds__(kBlockThreads, 4) void renderKernel(DevParams P, De
                 mode = kModeTrav;
             }
         }
+        if (COUNT) prof[10] += (unsigned)__popcll(__ballot(mode == kModeFinish));
         if (mode == kModeFinish) {
             accumulateSample(P, img, texel, ps);
             ps.k++;
             mode = kModeNew;
         }
+        if (COUNT) prof[11] += (unsigned)__popcll(__ballot(mode == kModeNew && ps.k < kEnd));
         if (mode == kModeNew) {
             if (ps.k < kEnd) {
                 v3 ro, rd;
@@ -449,6 +448,16 @@ __global__ __launch_bounds__(kBlockThreads, 4) void renderKernel(DevParams P, De
 
         // ============================================================== traversal phase
         for (;;) {
+            if (COUNT) {
+                const unsigned long long tm = __ballot(mode == kModeTrav);
+                const unsigned long long tri = __ballot(mode == kModeTrav && q.leafPos < q.leafEnd);
+                prof[0]++;
+                prof[1] += (unsigned)__popcll(tm);
+                if (tm & ~tri) prof[2]++;
+                prof[3] += (unsigned)__popcll(tm & ~tri);
+                if (tri) prof[4]++;
+                prof[5] += (unsigned)__popcll(tri);
+            }
             if (mode == kModeTrav) {
                 if (queryStep<COUNT>(S, q, stack, sc)) {
                     if (q.isShadow) {
@@ -483,6 +492,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void renderKernel(DevParams P, De
             atomicAdd(&counters->nodeVisits, (unsigned long long)sNodes);
             atomicAdd(&counters->triangleTests, (unsigned long long)sTris);
             atomicMax(&counters->maxStack, m);
+            for (int i = 0; i < 12; i++) atomicAdd(&counters->profile[i], prof[i]);
         }
     }
 }
@@ -600,40 +610,71 @@ __global__ __launch_bounds__(kBlockThreads) void traverseKernel(DevParams P, Dev
                                                                DevCounters* counters)
 {
     __shared__ int s_stack[STACK * kBlockThreads];
-    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    // finished extension queries wait here until a full wave's worth can be appended to the shade
+    // queue with one atomic (a contended global counter per finished ray would stall every step)
+    __shared__ unsigned s_done[kBlockThreads / 64][128];
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     int* stack = s_stack + tid;
+    volatile unsigned* done = s_done[wave];
     const unsigned total = *Q.rayInCount;
+    // Queue entries are reserved a chunk at a time per wave and handed to idle lanes from the
+    // wave's private range; chunks shrink with the queue so late, short iterations still spread.
+    const unsigned wavesInGrid = gridDim.x * (kBlockThreads / 64);
+    unsigned chunk = total / (wavesInGrid * 4u);
+    chunk = chunk < 64u ? 64u : (chunk > 512u ? 512u : chunk);
 
     unsigned nRays = 0, nSamples = 0;
     StepCounters sc{0u, 0u, 0u};
     Query q{};
-    bool busy = false, exhausted = false;  // `exhausted` is wave-uniform
+    bool busy = false;
     unsigned entry = 0;
+    // wave-uniform bookkeeping
+    bool exhausted = false;
+    unsigned poolPos = 0, poolEnd = 0, doneCount = 0;
+
+    auto flushDone = [&](unsigned n) {  // appends the first n (<= 64) buffered slots
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(Q.shadeCount, n);
+        base = __shfl(base, 0, 64);
+        if (lane < n) Q.shadeQ[base + lane] = done[lane];
+    };
 
     for (;;) {
-        // ---- refill: idle lanes take the next queue entries (one atomic per wave)
+        // ---- refill idle lanes
         const unsigned long long idle = __ballot(!busy);
-        const int nIdle = __popcll(idle);
-        if (!exhausted && (nIdle >= (int)P.refillMin || nIdle == 64)) {
-            const int leader = __ffsll((long long)idle) - 1;
-            unsigned base = 0;
-            if ((int)lane == leader) base = atomicAdd(Q.rayHead, (unsigned)nIdle);
-            base = __shfl(base, leader, 64);
-            if (base + (unsigned)nIdle >= total) exhausted = true;
-            if (!busy) {
-                const unsigned idx = base + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
-                if (idx < total) {
-                    entry = Q.rayIn[idx];
-                    const unsigned slot = entry & kEntrySlotMask;
-                    const float4 o = W.rayO[slot];
-                    const bool shadow = (entry & kEntryShadow) != 0u;
-                    const float4 d = shadow ? W.shDir[slot] : W.rayD[slot];
-                    beginQuery(q, P.rootRef, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), shadow);
-                    busy = true;
+        const unsigned nIdle = (unsigned)__popcll(idle);
+        if ((nIdle >= P.refillMin || nIdle == 64u) && !(exhausted && poolPos == poolEnd)) {
+            if (poolPos == poolEnd) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(Q.rayHead, chunk);
+                base = __shfl(base, 0, 64);
+                if (base >= total) {
+                    exhausted = true;
+                    poolPos = poolEnd = 0;
+                } else {
+                    poolPos = base;
+                    poolEnd = base + chunk < total ? base + chunk : total;
+                    if (poolEnd == total) exhausted = true;
                 }
             }
+            const unsigned avail = poolEnd - poolPos;
+            const unsigned take = nIdle < avail ? nIdle : avail;
+            const unsigned rank = (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!busy && rank < take) {
+                entry = Q.rayIn[poolPos + rank];
+                const unsigned slot = entry & kEntrySlotMask;
+                const float4 o = W.rayO[slot];
+                const bool shadow = (entry & kEntryShadow) != 0u;
+                const float4 d = shadow ? W.shDir[slot] : W.rayD[slot];
+                beginQuery(q, P.rootRef, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), shadow);
+                busy = true;
+            }
+            poolPos += take;
         }
-        if (__ballot(busy) == 0ull) break;  // nothing in flight: the refill above ran and found nothing
+        if (__ballot(busy) == 0ull) {
+            if (exhausted && poolPos == poolEnd) break;
+            continue;
+        }
 
         bool toShade = false;
         unsigned shadeSlot = 0;
@@ -672,8 +713,25 @@ __global__ __launch_bounds__(kBlockThreads) void traverseKernel(DevParams P, Dev
                 shadeSlot = slot;
             }
         }
-        waveAppend(toShade, shadeSlot, Q.shadeQ, Q.shadeCount);
+        // ---- buffer finished extension queries, flush 64 at a time
+        const unsigned long long fin = __ballot(toShade);
+        if (fin != 0ull) {
+            if (toShade) done[doneCount + (unsigned)__popcll(fin & ((1ull << lane) - 1ull))] = shadeSlot;
+            doneCount += (unsigned)__popcll(fin);
+            __builtin_amdgcn_wave_barrier();
+            if (doneCount >= 64u) {
+                flushDone(64u);
+                __builtin_amdgcn_wave_barrier();
+                const unsigned rem = doneCount - 64u;
+                const unsigned moved = lane < rem ? done[64u + lane] : 0u;
+                __builtin_amdgcn_wave_barrier();
+                if (lane < rem) done[lane] = moved;
+                doneCount = rem;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
     }
+    if (doneCount > 0u) flushDone(doneCount);
 
     const unsigned sRays = waveSum(nRays), sSamples = waveSum(nSamples);
     if (lane == 0 && (sRays | sSamples)) {

@@ -164,6 +164,13 @@ struct DevParams {
 struct DevCounters {
     unsigned long long samples, raysClosest, raysAny, nodeVisits, triangleTests, closestHits;
     unsigned int maxStack, pad;
+    // megakernel occupancy profile (counting build): wave-level iteration counts and the lanes
+    // that took part in them.  [0] traversal iterations, [1] lanes traversing in them,
+    // [2] iterations with a node step, [3] lanes in node steps, [4] iterations with a triangle
+    // step, [5] lanes in triangle steps, [6] shading phases with a hit/miss to shade, [7] lanes
+    // shading a hit, [8] lanes shading a miss, [9] shading phases, [10] lanes finishing a sample,
+    // [11] lanes starting a sample
+    unsigned long long profile[12];
 };
 
 }  // namespace ptcore

@@ -839,6 +839,19 @@ int pt_debug_set_tuning(pt_ctx* c, int key, int value)
     }
 }
 
+// Profiling hook: the 12 wave-occupancy counters of the most recent pt_dispatch_counted() with the
+// megakernel scheduler (see DevCounters::profile).
+int pt_debug_get_profile(pt_ctx* c, uint64_t out12[12])
+{
+    if (!c || !out12) return fail(PT_ERR_INVALID, "null argument");
+    DeviceGuard guard(c->device);
+    DevCounters h{};
+    HIP_TRY(hipMemcpyAsync(&h, c->dCounters.ptr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 12; i++) out12[i] = h.profile[i];
+    return PT_OK;
+}
+
 // Test hook (not part of the drop-in surface): evaluates one float32 building block of the
 // kernels element-wise on the device.  fn: 0 sin, 1 cos, 2 asin, 3 atan2(a,b), 4 pow(a,b),
 // 5 min, 6 max, 7 a/b, 8 sqrt, 9 1/sqrt.

@@ -113,6 +113,11 @@ class Renderer:
         for k, v in kw.items():
             check(self._lib.pt_debug_set_tuning(self._h, self.TUNING_KEYS[k], int(v)))
 
+    def profile(self):
+        out = (ctypes.c_uint64 * 12)()
+        check(self._lib.pt_debug_get_profile(self._h, out))
+        return list(out)
+
     def scale_images(self, scale):
         check(self._lib.pt_scale_images(self._h, float(scale)))
 

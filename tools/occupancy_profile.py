@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Wave-occupancy profile of the megakernel on the benchmark workload (counting build)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from pathtracer_amd import renderer as R  # noqa: E402
+
+
+class A:
+    subdivide = 0
+
+
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+work = bench.build_workload(A)
+g = R.Renderer(1920, 1080)
+g.upload_nodes(work["nodes"]); g.upload_primitives(work["prims"]); g.upload_materials(work["mats"])
+g.upload_environment(work["hdri"], work["cache"])
+p = R.default_params(1920, 1080)
+p.max_bounces = 8
+g.set_params(p)
+g.clear()
+g.dispatch(1, spp, 1, counted=True)
+g.synchronize()
+st, pr = g.stats(), g.profile()
+rays = st.rays_closest + st.rays_any
+print(f"rays {rays}  node visits/ray {st.node_visits / rays:.2f}  tri tests/ray {st.triangle_tests / rays:.2f}  ms {g.last_dispatch_ms():.2f}")
+print(f"traversal iterations {pr[0]}  avg lanes traversing {pr[1] / pr[0]:.1f}")
+print(f"  with node step   {pr[2]} ({pr[2] / pr[0]:.2%})  avg lanes {pr[3] / max(pr[2], 1):.1f}")
+print(f"  with triangle step {pr[4]} ({pr[4] / pr[0]:.2%})  avg lanes {pr[5] / max(pr[4], 1):.1f}")
+print(f"shading phases {pr[9]}  shading something {pr[6]}  hit lanes/phase {pr[7] / max(pr[6], 1):.1f}  miss lanes/phase {pr[8] / max(pr[6], 1):.1f}")
+print(f"  finish lanes/phase {pr[10] / pr[9]:.1f}  new-sample lanes/phase {pr[11] / pr[9]:.1f}")
+print(f"  traversal iterations per shading phase {pr[0] / pr[9]:.1f}")
