@@ -43,6 +43,12 @@
 namespace ptcore {
 
 constexpr int kBlockThreads = 256;
+// Waves per SIMD the megakernel is compiled for: 3 gives the register allocator 168 VGPRs (a
+// few dozen spilled values); 4 halves that budget and spills ~95, 5 spills ~185 -- both measured
+// slower than 3 on the benchmark scene.
+#ifndef PT_WAVES_PER_SIMD
+#define PT_WAVES_PER_SIMD 3
+#endif
 // Entry distance must exceed the best hit by this factor before a sub-tree is skipped: box and
 // triangle distances are rounded independently, the margin keeps a triangle whose computed
 // distance ties or narrowly beats the current best from being culled with its box.
@@ -364,7 +370,7 @@ PT_DEV unsigned waveMax(unsigned v)
 enum LaneMode : int { kModeNew = 0, kModeShade = 1, kModeTrav = 2, kModeFinish = 3, kModeDone = 4 };
 
 template <int STACK, bool COUNT>
-__global__ __launch_bounds__(kBlockThreads, 4) void renderKernel(DevParams P, DevScene S, Images img, DevCounters* counters)
+__global__ __launch_bounds__(kBlockThreads, PT_WAVES_PER_SIMD) void renderKernel(DevParams P, DevScene S, Images img, DevCounters* counters)
 {
     __shared__ int s_stack[STACK * kBlockThreads];
     const unsigned tid = threadIdx.x;
