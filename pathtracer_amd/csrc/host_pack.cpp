@@ -108,10 +108,11 @@ std::string PackScene(const RefNodeAlign* nodes, size_t nodeCount, const RefPrim
     };
     std::vector<Item> stack;
     out.nodes.reserve(nodeCount / 2 + 1);
+    out.nodes.push_back(DevNode{});  // index 0 stays unused: the kernels read reference 0 as "no node"
     out.nodes.push_back(DevNode{});
-    stack.push_back({1, 0, 1});
+    stack.push_back({1, 1, 1});
     seen[1] = 1;
-    out.rootRef = 0;
+    out.rootRef = 1;
     while (!stack.empty()) {
         Item it = stack.back();
         stack.pop_back();

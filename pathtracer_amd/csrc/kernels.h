@@ -28,7 +28,7 @@
 //     radiance, BSDF value, MIS weight) does not depend on the ray's outcome, so it is
 //     evaluated up front into a pending contribution that the shadow query merely gates.
 //   * The per-lane stack of postponed far children lives in LDS (entry k of thread t at word
-//     k*256 + t: consecutive lanes hit consecutive banks) with its newest entry cached in a
+//     k*blockDim + t: consecutive lanes hit consecutive banks) with its newest entry cached in a
 //     register; the near child is followed directly.
 //
 // Same results as the reference shader's traversal (intersection.glsl:115-199,230-315):
@@ -49,6 +49,12 @@ constexpr int kBlockThreads = 256;
 #ifndef PT_WAVES_PER_SIMD
 #define PT_WAVES_PER_SIMD 3
 #endif
+// Threads per megakernel block: 64 (one wave, one 8x8 pixel tile) or 256 (a 16x16 tile).
+#ifndef PT_MEGA_THREADS
+#define PT_MEGA_THREADS 64
+#endif
+constexpr int kMegaThreads = PT_MEGA_THREADS;
+constexpr unsigned kMegaTile = kMegaThreads == 64 ? 8u : 16u;  // tile edge in pixels
 // Entry distance must exceed the best hit by this factor before a sub-tree is skipped: box and
 // triangle distances are rounded independently, the margin keeps a triangle whose computed
 // distance ties or narrowly beats the current best from being culled with its box.
@@ -94,36 +100,61 @@ PT_DEV void beginQuery(Query& q, int rootRef, v3 ro, v3 rd, bool isShadow)
     q.cur = rootRef;
     q.leafPos = q.leafEnd = 0;
     q.isShadow = isShadow;
-    if (rootRef < 0) {
-        const unsigned bits = ~(unsigned)rootRef;
-        q.leafPos = bits >> 3;
-        q.leafEnd = q.leafPos + (bits & 7u) + 1u;
-        q.cur = 0;
-    }
 }
 
-// Advances the query by one step -- one triangle of the current leaf, or one interior node (both
-// children's boxes) -- and returns true when the query is complete.  `stack` points at this
-// thread's column of the block's LDS stack.
-template <bool COUNT>
+// Advances the query by one iteration and returns true when the query is complete.  A lane can
+// hold an interior node to visit (`cur` > 0) and, next to it, a leaf whose triangles are still
+// being scanned (`leafPos` < `leafEnd`): reaching a leaf does not interrupt the walk, the leaf is
+// parked and its triangles are tested one per iteration while the lane goes on visiting nodes.  A
+// second leaf reference waits in `cur` (< 0) until the parked leaf is done, so leaves are scanned
+// in the order they were reached and triangles in leaf order.  The node and the triangle record
+// are fetched together before either is used: one memory round trip per iteration.  (Holding the
+// triangle half back until several lanes of the wave have a leaf was measured: every threshold
+// above one lane is slower, the lanes that wait cost more than the fuller triangle steps save.)
+// `stack` points at this thread's column of the block's LDS stack (entries STRIDE words apart).
+template <bool COUNT, int STRIDE = kBlockThreads>
 PT_DEV bool queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc)
 {
-    // One 64-byte fetch per step, whichever record the lane needs: the current leaf's next
-    // triangle (48 B + 16 B of the following record) or the current interior node.  Issuing it
-    // before the step diverges puts one memory round trip, not two, on the wave's critical path.
-    const bool atTriangle = q.leafPos < q.leafEnd;
-    const float4* rec = atTriangle ? reinterpret_cast<const float4*>(S.triangles + q.leafPos)
-                                   : reinterpret_cast<const float4*>(S.nodes + q.cur);
-    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+    const bool hasNode = q.cur > 0;
+    const bool doTri = q.leafPos < q.leafEnd;
+    float4 n0, n1, n2, n3, t0, t1, t2;
+    if (hasNode) {
+        const float4* rec = reinterpret_cast<const float4*>(S.nodes + q.cur);
+        n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
+    }
+    if (doTri) {
+        const float4* rec = reinterpret_cast<const float4*>(S.triangles + q.leafPos);
+        t0 = rec[0], t1 = rec[1], t2 = rec[2];
+    }
     bool finished = false;  // query complete
-    bool pop = false;       // this step ends with taking the next sub-tree off the stack
-    if (atTriangle) {
+    bool pop = false;
+    if (hasNode) {
+        if (COUNT) sc.nodeVisits++;
+        float t0l, t0r;
+        const float dl = hitAabb(q.ro, q.inv, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, t0l);
+        const float dr = hitAabb(q.ro, q.inv, n2.x, n2.y, n2.z, n3.x, n3.y, n3.z, t0r);
+        const float limit = q.bestT * kPruneMargin;  // bestT stays FLT_MAX for shadow rays
+        const bool hl = dl > 0.0f && !(t0l > limit);
+        const bool hr = dr > 0.0f && !(t0r > limit);
+        const int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
+        const bool both = hl && hr;
+        const bool leftFirst = dl < dr;  // intersection.glsl:169-180
+        if (both) {  // postpone the far child
+            if (q.sp > 0) stack[(q.sp - 1) * STRIDE] = q.top;
+            q.top = leftFirst ? right : left;
+            q.sp++;
+            if (COUNT) sc.maxStack = (unsigned)q.sp > sc.maxStack ? (unsigned)q.sp : sc.maxStack;
+        }
+        q.cur = both ? (leftFirst ? left : right) : (hl ? left : right);
+        pop = !(hl || hr);
+    }
+    if (doTri) {
         // Moller-Trumbore with the shader's expressions (intersection.glsl:26-40); the edges and
         // their cross product come precomputed from the host.
         if (COUNT) sc.triangleTests++;
-        const v3 n = mk3(r0.w, r1.w, r2.w);
-        const v3 ab = mk3(r1.x, r1.y, r1.z), ac = mk3(r2.x, r2.y, r2.z);
-        const v3 ao = q.ro - mk3(r0.x, r0.y, r0.z);
+        const v3 n = mk3(t0.w, t1.w, t2.w);
+        const v3 ab = mk3(t1.x, t1.y, t1.z), ac = mk3(t2.x, t2.y, t2.z);
+        const v3 ao = q.ro - mk3(t0.x, t0.y, t0.z);
         const v3 dao = cross(ao, q.rd);
         const float det = -dot(q.rd, n);
         const float invDet = 1.0f / det;
@@ -139,40 +170,21 @@ PT_DEV bool queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc)
         q.bestPrim = better ? (int)q.leafPos : q.bestPrim;
         q.leafPos++;
         finished = q.isShadow && ok;  // occluded
-        pop = !finished && q.leafPos == q.leafEnd;
-    } else {
-        if (COUNT) sc.nodeVisits++;
-        float t0l, t0r;
-        const float dl = hitAabb(q.ro, q.inv, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, t0l);
-        const float dr = hitAabb(q.ro, q.inv, r2.x, r2.y, r2.z, r3.x, r3.y, r3.z, t0r);
-        const float limit = q.bestT * kPruneMargin;  // bestT stays FLT_MAX for shadow rays
-        const bool hl = dl > 0.0f && !(t0l > limit);
-        const bool hr = dr > 0.0f && !(t0r > limit);
-        const int left = __float_as_int(r0.w), right = __float_as_int(r1.w);
-        const bool both = hl && hr;
-        const bool leftFirst = dl < dr;  // intersection.glsl:169-180
-        if (both) {  // postpone the far child
-            if (q.sp > 0) stack[(q.sp - 1) * kBlockThreads] = q.top;
-            q.top = leftFirst ? right : left;
-            q.sp++;
-            if (COUNT) sc.maxStack = (unsigned)q.sp > sc.maxStack ? (unsigned)q.sp : sc.maxStack;
-        }
-        q.cur = both ? (leftFirst ? left : right) : (hl ? left : right);
-        pop = !(hl || hr);
     }
-    if (pop) {
-        finished = q.sp == 0;
-        q.cur = q.top;
-        q.sp = finished ? 0 : q.sp - 1;
-        if (q.sp > 0) q.top = stack[(q.sp - 1) * kBlockThreads];
+    if (pop) {  // both children missed: next sub-tree off the stack
+        q.cur = q.sp > 0 ? q.top : 0;
+        q.sp = q.sp > 0 ? q.sp - 1 : 0;
+        if (q.sp > 0) q.top = stack[(q.sp - 1) * STRIDE];
     }
-    if (!finished && q.cur < 0 && q.leafPos == q.leafEnd) {  // arrived at a leaf reference
+    if (q.cur < 0 && q.leafPos == q.leafEnd) {  // park the leaf `cur` refers to, walk on
         const unsigned bits = ~(unsigned)q.cur;
         q.leafPos = bits >> 3;
         q.leafEnd = q.leafPos + (bits & 7u) + 1u;
-        q.cur = 0;
+        q.cur = q.sp > 0 ? q.top : 0;
+        q.sp = q.sp > 0 ? q.sp - 1 : 0;
+        if (q.sp > 0) q.top = stack[(q.sp - 1) * STRIDE];
     }
-    return finished;
+    return finished || (q.cur == 0 && q.leafPos == q.leafEnd);
 }
 
 // ------------------------------------------------------------------------------ path logic
@@ -370,9 +382,9 @@ PT_DEV unsigned waveMax(unsigned v)
 enum LaneMode : int { kModeNew = 0, kModeShade = 1, kModeTrav = 2, kModeFinish = 3, kModeDone = 4 };
 
 template <int STACK, bool COUNT>
-__global__ __launch_bounds__(kBlockThreads, PT_WAVES_PER_SIMD) void renderKernel(DevParams P, DevScene S, Images img, DevCounters* counters)
+__global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(DevParams P, DevScene S, Images img, DevCounters* counters)
 {
-    __shared__ int s_stack[STACK * kBlockThreads];
+    __shared__ int s_stack[STACK * kMegaThreads];
     const unsigned tid = threadIdx.x;
     int* stack = s_stack + tid;
 
@@ -381,8 +393,8 @@ __global__ __launch_bounds__(kBlockThreads, PT_WAVES_PER_SIMD) void renderKernel
     const unsigned tile = blockIdx.x;
     const unsigned tileX = tile % P.tilesX, tileY = tile / P.tilesX;
     const unsigned wave = tid >> 6, lane = tid & 63u;
-    const unsigned px = tileX * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const unsigned py = tileY * 16u + (wave >> 1) * 8u + (lane >> 3);
+    const unsigned px = tileX * kMegaTile + (wave & 1u) * 8u + (lane & 7u);
+    const unsigned py = tileY * kMegaTile + (wave >> 1) * 8u + (lane >> 3);
     const bool inside = px < P.width && py < P.height;
     const size_t texel = (size_t)py * P.width + px;
 
@@ -456,16 +468,18 @@ __global__ __launch_bounds__(kBlockThreads, PT_WAVES_PER_SIMD) void renderKernel
         for (;;) {
             if (COUNT) {
                 const unsigned long long tm = __ballot(mode == kModeTrav);
-                const unsigned long long tri = __ballot(mode == kModeTrav && q.leafPos < q.leafEnd);
+                const unsigned long long nodeM = __ballot(mode == kModeTrav && q.cur > 0);
+                const unsigned long long leafM = __ballot(mode == kModeTrav && q.leafPos < q.leafEnd);
+                const unsigned long long tri = leafM;
                 prof[0]++;
                 prof[1] += (unsigned)__popcll(tm);
-                if (tm & ~tri) prof[2]++;
-                prof[3] += (unsigned)__popcll(tm & ~tri);
+                if (nodeM) prof[2]++;
+                prof[3] += (unsigned)__popcll(nodeM);
                 if (tri) prof[4]++;
                 prof[5] += (unsigned)__popcll(tri);
             }
             if (mode == kModeTrav) {
-                if (queryStep<COUNT>(S, q, stack, sc)) {
+                if (queryStep<COUNT, kMegaThreads>(S, q, stack, sc)) {
                     if (q.isShadow) {
                         if (q.bestPrim < 0) ps.radiance = ps.radiance + pending;  // unoccluded
                         if (hasExt) {
@@ -480,7 +494,7 @@ __global__ __launch_bounds__(kBlockThreads, PT_WAVES_PER_SIMD) void renderKernel
                     }
                 }
             }
-            if (__popcll(__ballot(mode == kModeTrav)) < threshold) break;
+            if ((int)__popcll(__ballot(mode == kModeTrav)) < threshold) break;
         }
     }
 

@@ -355,8 +355,8 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
     P.envW = c->envW;
     P.envH = c->envH;
     P.rootRef = c->rootRef;
-    P.tilesX = (uint32_t)((c->width + 15) / 16);
-    P.tilesY = (uint32_t)((c->height + 15) / 16);
+    P.tilesX = (uint32_t)((c->width + kMegaTile - 1) / kMegaTile);
+    P.tilesY = (uint32_t)((c->height + kMegaTile - 1) / kMegaTile);
 
     DevScene S{};
     S.nodes = (const DevNode*)c->dNodes.ptr;
@@ -372,13 +372,12 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
     P.travExitNum = c->travExitNum;
     P.refillMin = c->refillMin;
     HIP_TRY(hipMemsetAsync(c->dCounters.ptr, 0, sizeof(DevCounters), c->stream));
-    const dim3 block(kBlockThreads);
     DevCounters* ctr = (DevCounters*)c->dCounters.ptr;
     Images img{imagePtr(c, 0), imagePtr(c, 1), imagePtr(c, 2)};
     const bool deep = c->maxDepth > 32;
     HIP_TRY(hipEventRecord(c->evStart, c->stream));
     if (c->pipeline == 0) {
-        const dim3 grid(P.tilesX * P.tilesY);
+        const dim3 grid(P.tilesX * P.tilesY), block(kMegaThreads);
         if (counted) {
             if (deep)
                 hipLaunchKernelGGL((renderKernel<64, true>), grid, block, 0, c->stream, P, S, img, ctr);
