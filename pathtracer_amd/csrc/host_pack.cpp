@@ -96,6 +96,7 @@ std::string PackScene(const RefNodeAlign* nodes, size_t nodeCount, const RefPrim
     std::string err;
     const RefNodeAlign& root = nodes[1];
     if (root.n > 0) {
+        out.nodes.push_back(DevNode{});  // node 0 must exist: idle lanes fetch it
         out.rootRef = leafRef(root, 1, err);
         out.maxDepth = 0;
         return err;

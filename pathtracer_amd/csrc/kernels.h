@@ -117,15 +117,13 @@ PT_DEV bool queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc)
 {
     const bool hasNode = q.cur > 0;
     const bool doTri = q.leafPos < q.leafEnd;
-    float4 n0, n1, n2, n3, t0, t1, t2;
-    if (hasNode) {
-        const float4* rec = reinterpret_cast<const float4*>(S.nodes + q.cur);
-        n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
-    }
-    if (doTri) {
-        const float4* rec = reinterpret_cast<const float4*>(S.triangles + q.leafPos);
-        t0 = rec[0], t1 = rec[1], t2 = rec[2];
-    }
+    // Both records are requested up front by every calling lane -- record 0 of either array (always
+    // allocated) stands in when the lane has no node or no leaf -- so the loads sit in straight-line
+    // code and are all in flight before the first use.
+    const float4* nrec = reinterpret_cast<const float4*>(S.nodes + (hasNode ? q.cur : 0));
+    const float4* trec = reinterpret_cast<const float4*>(S.triangles + (doTri ? q.leafPos : 0u));
+    const float4 n0 = nrec[0], n1 = nrec[1], n2 = nrec[2], n3 = nrec[3];
+    const float4 t0 = trec[0], t1 = trec[1], t2 = trec[2];
     bool finished = false;  // query complete
     bool pop = false;
     if (hasNode) {

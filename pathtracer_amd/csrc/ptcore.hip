@@ -148,7 +148,7 @@ int syncScene(pt_ctx* c)
         const size_t nb = packed.nodes.size() * sizeof(DevNode), tb = packed.triangles.size() * sizeof(DevTriangle),
                      sb = packed.shading.size() * sizeof(DevShading);
         HIP_TRY(c->dNodes.ensure(nb));
-        HIP_TRY(c->dTriangles.ensure(tb + 16));  // a triangle step fetches 64 B from a 48-B record
+        HIP_TRY(c->dTriangles.ensure(tb));
         HIP_TRY(c->dShading.ensure(sb));
         if (nb) HIP_TRY(hipMemcpyAsync(c->dNodes.ptr, packed.nodes.data(), nb, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->dTriangles.ptr, packed.triangles.data(), tb, hipMemcpyHostToDevice, c->stream));
