@@ -158,11 +158,14 @@ def main():
         total_spp = args.steps * S * world
         avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
         achieved = bytes_per_launch / avg_kernel_s / 1e9
+        # PMC-measured bytes per launch, valid only for the launch shape it was collected on
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("bytes_per_launch")
+                t = json.load(open(tpath))
+                if (t.get("width"), t.get("height"), t.get("spp_per_step"), t.get("max_bounces")) == (W, H, S, args.bounces):
+                    traffic = t.get("bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
