@@ -176,6 +176,34 @@ int pt_align_nodes(const void* nodes40, size_t count, void* nodes48_out);
 int pt_align_primitives(const void* prims100, size_t count, void* prims112_out);
 /* CalculateHdriCache (PathTracingRenderer.cpp:803-901): cache_out = w*h*3 floats. */
 int pt_calculate_hdri_cache(const float* hdri_rgb, int width, int height, float* cache_out);
+
+/* glTF 2.0 / GLB scene reader: what ModelLoader::Load (ModelLoader.cpp:83-121) hands to
+ * PathTracingRenderer::AddPathTracingModel, without assimp.  One sub-mesh per mesh primitive, in file
+ * order; node transforms are ignored as in the reference; vertices are {pos, nor, uv} with V flipped
+ * (v -> 1 - v) as the reference's importer does for glTF.  PT_ERR_SCENE (message via
+ * pt_last_error) for unreadable files, non-triangle primitives, sparse accessors, a primitive
+ * without TEXCOORD_0 (the reference throws there too: ModelLoader.cpp:389-403). */
+typedef struct pt_gltf pt_gltf;
+int pt_gltf_load(const char* path, pt_gltf** out);
+void pt_gltf_free(pt_gltf* scene);
+int pt_gltf_submesh_count(const pt_gltf* scene, uint32_t* count_out);
+int pt_gltf_submesh_size(const pt_gltf* scene, uint32_t submesh, uint64_t* vertex_count_out, uint64_t* index_count_out);
+/* vertices32_out: vertex_count x 32 B {pos3, nor3, uv2}; indices_out: index_count x u32. */
+int pt_gltf_submesh_read(const pt_gltf* scene, uint32_t submesh, void* vertices32_out, uint32_t* indices_out);
+/* ModelLoader::GenerateMaterial (ModelLoader.cpp:150-287).  attributes18_out: the 18 floats of
+ * Material::MaterialAttributes in declaration order (Material.h:43-59: emission3, albedo3, specular,
+ * specularTint, metallic, roughness, subsurface, anisotropy, sheenRoughness, sheenTint, clearcoat,
+ * clearcoatRoughness, refraction, transmission).  images11_out: per Material::MaterialTextureSlot the
+ * index of the image to load, or -1.  Slot formats as the reference requests them
+ * (ModelLoader.cpp:201-231): albedo sRGB8; specular and sheen-roughness RGBA8; the others RGB8;
+ * all loaded flipped vertically (PathTracingApplication.cpp:212). */
+int pt_gltf_submesh_material(const pt_gltf* scene, uint32_t submesh, float attributes18_out[18], int32_t images11_out[11]);
+int pt_gltf_image_count(const pt_gltf* scene, uint32_t* count_out);
+/* Where image `image` comes from: *path_out = file to decode (NULL when embedded), else
+ * *bytes_out / *byte_count_out = the encoded (PNG/JPEG) bytes, owned by `scene`.  Decoding images is
+ * the caller's job, as it is stb_image's in the reference. */
+int pt_gltf_image_source(const pt_gltf* scene, uint32_t image, const char** path_out, const void** bytes_out,
+                         uint64_t* byte_count_out);
 /* glm::lookAt / glm::perspective (right-handed, -1..1 depth) / glm::inverse, as used by
  * Runtime/Camera/Camera.cpp:10-18 and PathTracingApplication.cpp:233-235,250. */
 void pt_look_at(const float eye[3], const float center[3], const float up[3], float out16[16]);

@@ -39,4 +39,30 @@ std::string PackScene(const RefNodeAlign* nodes, size_t nodeCount, const RefPrim
 std::string PackMaterials(const RefMaterialAlign* mats, size_t count, size_t textureSlots,
                           const std::vector<int>& slotToTexture, std::vector<DevMaterial>& out);
 
+// host_gltf.cpp: glTF 2.0 / GLB reader (ModelLoader::Load + GenerateMaterial without assimp).
+struct GltfMaterial {  // Material::MaterialAttributes (Material.h:43-59), same order and defaults
+    float emission[3] = {0.0f, 0.0f, 0.0f};
+    float albedo[3] = {1.0f, 1.0f, 1.0f};
+    float specular = 1.0f, specularTint = 0.0f, metallic = 0.0f, roughness = 1.0f, subsurface = 0.0f, anisotropy = 0.0f,
+          sheenRoughness = 0.0f, sheenTint = 0.0f, clearcoat = 0.0f, clearcoatRoughness = 0.0f, refraction = 1.5f,
+          transmission = 0.0f;
+    int32_t image[11] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};  // per Material::MaterialTextureSlot
+};
+static_assert(offsetof(GltfMaterial, image) == 18 * sizeof(float), "attributes are 18 packed floats");
+struct GltfSubmesh {
+    std::vector<RefVertex> vertices;
+    std::vector<uint32_t> indices;
+    GltfMaterial material;
+};
+struct GltfImage {
+    std::string path;            // file to decode, or
+    std::vector<uint8_t> bytes;  // the encoded image itself (GLB / data URI)
+};
+struct GltfScene {
+    std::vector<GltfSubmesh> submeshes;
+    std::vector<GltfImage> images;
+};
+// Returns empty string on success, else what is wrong with the file.
+std::string LoadGltf(const std::string& path, GltfScene& scene);
+
 }  // namespace ptcore

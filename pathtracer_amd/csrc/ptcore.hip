@@ -684,6 +684,83 @@ int pt_calculate_hdri_cache(const float* hdri, int width, int height, float* cac
     return PT_OK;
 }
 
+struct pt_gltf {
+    GltfScene scene;
+};
+
+int pt_gltf_load(const char* path, pt_gltf** out)
+{
+    if (!path || !out) return fail(PT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    std::unique_ptr<pt_gltf> g(new (std::nothrow) pt_gltf());
+    if (!g) return fail(PT_ERR_NOMEM, "out of host memory");
+    std::string err;
+    try {
+        err = LoadGltf(path, g->scene);
+    } catch (const std::bad_alloc&) {
+        return fail(PT_ERR_NOMEM, "out of host memory while reading the glTF file");
+    }
+    if (!err.empty()) return fail(PT_ERR_SCENE, err);
+    *out = g.release();
+    return PT_OK;
+}
+
+void pt_gltf_free(pt_gltf* g) { delete g; }
+
+int pt_gltf_submesh_count(const pt_gltf* g, uint32_t* count)
+{
+    if (!g || !count) return fail(PT_ERR_INVALID, "null argument");
+    *count = (uint32_t)g->scene.submeshes.size();
+    return PT_OK;
+}
+
+int pt_gltf_submesh_size(const pt_gltf* g, uint32_t submesh, uint64_t* vertexCount, uint64_t* indexCount)
+{
+    if (!g || !vertexCount || !indexCount) return fail(PT_ERR_INVALID, "null argument");
+    if (submesh >= g->scene.submeshes.size()) return fail(PT_ERR_INVALID, "sub-mesh index out of range");
+    *vertexCount = g->scene.submeshes[submesh].vertices.size();
+    *indexCount = g->scene.submeshes[submesh].indices.size();
+    return PT_OK;
+}
+
+int pt_gltf_submesh_read(const pt_gltf* g, uint32_t submesh, void* vertices, uint32_t* indices)
+{
+    if (!g || !vertices || !indices) return fail(PT_ERR_INVALID, "null argument");
+    if (submesh >= g->scene.submeshes.size()) return fail(PT_ERR_INVALID, "sub-mesh index out of range");
+    const GltfSubmesh& sm = g->scene.submeshes[submesh];
+    std::memcpy(vertices, sm.vertices.data(), sm.vertices.size() * sizeof(RefVertex));
+    std::memcpy(indices, sm.indices.data(), sm.indices.size() * sizeof(uint32_t));
+    return PT_OK;
+}
+
+int pt_gltf_submesh_material(const pt_gltf* g, uint32_t submesh, float attributes[18], int32_t images[11])
+{
+    if (!g || !attributes || !images) return fail(PT_ERR_INVALID, "null argument");
+    if (submesh >= g->scene.submeshes.size()) return fail(PT_ERR_INVALID, "sub-mesh index out of range");
+    const GltfMaterial& m = g->scene.submeshes[submesh].material;
+    std::memcpy(attributes, &m, 18 * sizeof(float));
+    std::memcpy(images, m.image, sizeof(m.image));
+    return PT_OK;
+}
+
+int pt_gltf_image_count(const pt_gltf* g, uint32_t* count)
+{
+    if (!g || !count) return fail(PT_ERR_INVALID, "null argument");
+    *count = (uint32_t)g->scene.images.size();
+    return PT_OK;
+}
+
+int pt_gltf_image_source(const pt_gltf* g, uint32_t image, const char** path, const void** bytes, uint64_t* byteCount)
+{
+    if (!g || !path || !bytes || !byteCount) return fail(PT_ERR_INVALID, "null argument");
+    if (image >= g->scene.images.size()) return fail(PT_ERR_INVALID, "image index out of range");
+    const GltfImage& img = g->scene.images[image];
+    *path = img.path.empty() ? nullptr : img.path.c_str();
+    *bytes = img.bytes.empty() ? nullptr : img.bytes.data();
+    *byteCount = img.bytes.size();
+    return PT_OK;
+}
+
 void pt_look_at(const float eye[3], const float center[3], const float up[3], float out16[16]) { LookAt(eye, center, up, out16); }
 void pt_perspective(float fovy, float aspect, float zNear, float zFar, float out16[16]) { Perspective(fovy, aspect, zNear, zFar, out16); }
 void pt_inverse4(const float in16[16], float out16[16]) { Inverse4(in16, out16); }

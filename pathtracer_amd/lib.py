@@ -85,6 +85,18 @@ SYMBOLS = {
     "pt_align_nodes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "pt_align_primitives": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "pt_calculate_hdri_cache": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "pt_gltf_load": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "pt_gltf_free": (None, [ctypes.c_void_p]),
+    "pt_gltf_submesh_count": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]),
+    "pt_gltf_submesh_size": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64),
+                                            ctypes.POINTER(ctypes.c_uint64)]),
+    "pt_gltf_submesh_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p,
+                                            ctypes.POINTER(ctypes.c_uint32)]),
+    "pt_gltf_submesh_material": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, c_float_p,
+                                                ctypes.POINTER(ctypes.c_int32)]),
+    "pt_gltf_image_count": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]),
+    "pt_gltf_image_source": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_char_p),
+                                            ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]),
     "pt_look_at": (None, [c_float_p, c_float_p, c_float_p, c_float_p]),
     "pt_perspective": (None, [ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_float_p]),
     "pt_inverse4": (None, [c_float_p, c_float_p]),

@@ -111,6 +111,39 @@ def flatten(recipe_list):
     return meshes, mats
 
 
+def sphere_field(grid=8, spacing=2.5, radius=1.0, seed=1, levels=1):
+    """Synthetic divergence workload: grid x grid spheres (the reference's Icosphere mesh, midpoint
+    subdivided `levels` times, vertices pushed out to the sphere) resting on the floor, one material
+    per sphere drawn from a seeded PCG64 stream: roughness U[0.05, 1], metallic 0 or 1, albedo
+    U[0.1, 0.9]^3.  The reference has no instancing, so every sphere is its own sub-mesh.
+    -> (list of (vertices, indices)), materials array; the floor is the last sub-mesh."""
+    v0, i0 = load_ptm("icosphere")
+    if levels:
+        v0, i0 = subdivide(v0, i0, levels)
+    p = v0[:, :3].astype(np.float64)
+    p /= np.linalg.norm(p, axis=1, keepdims=True)
+    v0 = v0.copy()
+    v0[:, :3] = p
+    v0[:, 3:6] = p
+    rng = np.random.default_rng(seed)
+    meshes, mats = [], []
+    for gz in range(grid):
+        for gx in range(grid):
+            v = v0.copy()
+            centre = np.array([(gx - 0.5 * (grid - 1)) * spacing, radius, (gz - 0.5 * (grid - 1)) * spacing])
+            v[:, :3] = (p * radius + centre).astype(np.float32)
+            meshes.append((v, i0))
+            mats.append(material(albedo=tuple(rng.uniform(0.1, 0.9, 3).astype(np.float32)),
+                                 roughness=np.float32(rng.uniform(0.05, 1.0)), metallic=float(rng.integers(0, 2))))
+    fv, fi = load_ptm("floor")
+    if grid * spacing > 18.0:  # Floor.glb spans +-10
+        fv = fv.copy()
+        fv[:, [0, 2]] *= np.float32(grid * spacing / 18.0)
+    meshes.append((fv, fi))
+    mats.append(floor_material())
+    return meshes, np.array(mats, dtype=MATERIAL_DTYPE)
+
+
 def subdivide(vertices, indices, levels=1):
     """Midpoint subdivision (each triangle -> 4), attributes interpolated, normals renormalised.
     Used to grow the bunny towards the triangle count of the reference's missing Dragon mesh."""

@@ -22,6 +22,13 @@ def built_scene(recipe_name):
     return R.align_nodes(nodes40), R.align_primitives(prims_sorted), mats
 
 
+def built_meshes(meshes, mats):
+    """Same as built_scene for an explicit list of (vertices, indices) sub-meshes."""
+    prims100 = np.concatenate([R.assemble_primitives(v, i, k) for k, (v, i) in enumerate(meshes)])
+    prims_sorted, nodes40 = R.build_bvh_sah(prims100, 4)
+    return R.align_nodes(nodes40), R.align_primitives(prims_sorted), mats
+
+
 @functools.lru_cache(maxsize=4)
 def environment(width=256, height=128):
     hdri = scenes.sky_hdri(width, height)

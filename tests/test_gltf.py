@@ -1,0 +1,213 @@
+"""The product's glTF / GLB reader against files written by the test itself: geometry extraction
+(strides, index widths, V flip, generated normals), the ModelLoader::GenerateMaterial mapping
+(Source/Runtime/Asset/ModelLoader.cpp:235-284 on top of Material.h:43-59 defaults) and the
+reference's error behaviour, plus the committed scene fixtures."""
+import base64
+import io
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from pathtracer_amd import gltf
+from pathtracer_amd.lib import PtError
+
+SCENES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes")
+
+
+def _quad_document(index_type=5123, with_normals=True, with_uv=True, stride=0, materials=None, material=None,
+                   mode=None, images=None, textures=None):
+    pos = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], "<f4")
+    nor = np.tile(np.array([[0, 0, 1]], "<f4"), (4, 1))
+    uv = np.array([[0, 0], [1, 0], [1, 0.25], [0, 1]], "<f4")
+    idx = np.array([0, 1, 2, 0, 2, 3], {5121: "<u1", 5123: "<u2", 5125: "<u4"}[index_type])
+    blob, views, accessors = b"", [], []
+
+    def add(data, target, comp, typ, count, byte_stride=0):
+        nonlocal blob
+        while len(blob) % 4:
+            blob += b"\0"
+        view = {"buffer": 0, "byteOffset": len(blob), "byteLength": len(data), "target": target}
+        if byte_stride:
+            view["byteStride"] = byte_stride
+        views.append(view)
+        accessors.append({"bufferView": len(views) - 1, "componentType": comp, "count": count, "type": typ})
+        blob += data
+        return len(accessors) - 1
+
+    attrs = {}
+    if stride:  # positions interleaved with 4 bytes of padding per vertex
+        padded = np.zeros((4, stride // 4), "<f4")
+        padded[:, :3] = pos
+        attrs["POSITION"] = add(padded.tobytes(), 34962, 5126, "VEC3", 4, stride)
+    else:
+        attrs["POSITION"] = add(pos.tobytes(), 34962, 5126, "VEC3", 4)
+    if with_normals:
+        attrs["NORMAL"] = add(nor.tobytes(), 34962, 5126, "VEC3", 4)
+    if with_uv:
+        attrs["TEXCOORD_0"] = add(uv.tobytes(), 34962, 5126, "VEC2", 4)
+    prim = {"attributes": attrs, "indices": add(idx.tobytes(), 34963, index_type, "SCALAR", 6)}
+    if material is not None:
+        prim["material"] = material
+    if mode is not None:
+        prim["mode"] = mode
+    doc = {"asset": {"version": "2.0"}, "meshes": [{"primitives": [prim]}], "accessors": accessors,
+           "bufferViews": views, "buffers": [{"byteLength": len(blob)}]}
+    if materials is not None:
+        doc["materials"] = materials
+    if images is not None:
+        doc["images"] = images
+        doc["textures"] = textures
+    return doc, blob, (pos, nor, uv, idx)
+
+
+def _write_gltf(tmp_path, doc, blob, name="scene", embed=False):
+    doc = json.loads(json.dumps(doc))
+    if embed:
+        doc["buffers"][0]["uri"] = "data:application/octet-stream;base64," + base64.b64encode(blob).decode()
+    else:
+        doc["buffers"][0]["uri"] = name + " data.bin".replace(" ", "%20")
+        (tmp_path / (name + " data.bin")).write_bytes(blob)
+    path = tmp_path / (name + ".gltf")
+    path.write_text(json.dumps(doc, indent=1))
+    return str(path)
+
+
+def _write_glb(tmp_path, doc, blob, name="scene"):
+    js = json.dumps(doc).encode()
+    js += b" " * (-len(js) % 4)
+    blob = blob + b"\0" * (-len(blob) % 4)
+    total = 12 + 8 + len(js) + 8 + len(blob)
+    data = struct.pack("<III", 0x46546C67, 2, total) + struct.pack("<II", len(js), 0x4E4F534A) + js
+    data += struct.pack("<II", len(blob), 0x004E4942) + blob
+    path = tmp_path / (name + ".glb")
+    path.write_bytes(data)
+    return str(path)
+
+
+@pytest.mark.parametrize("container", ["gltf+bin", "gltf+datauri", "glb"])
+@pytest.mark.parametrize("index_type", [5121, 5123, 5125])
+def test_geometry_round_trip(tmp_path, container, index_type):
+    doc, blob, (pos, nor, uv, idx) = _quad_document(index_type=index_type, stride=16)
+    if container == "glb":
+        path = _write_glb(tmp_path, doc, blob)
+    else:
+        path = _write_gltf(tmp_path, doc, blob, embed=container == "gltf+datauri")
+    s = gltf.load(path)
+    assert len(s.submeshes) == 1 and s.triangle_count() == 2
+    v, i = s.submeshes[0]
+    assert i.dtype == np.uint32 and i.tolist() == idx.tolist()
+    assert np.array_equal(v[:, 0:3], pos) and np.array_equal(v[:, 3:6], nor)
+    assert np.array_equal(v[:, 6], uv[:, 0])
+    assert np.array_equal(v[:, 7], np.float32(1.0) - uv[:, 1])  # the reference's importer flips V
+
+
+def test_default_material_and_material_without_extensions(tmp_path):
+    # no material on the primitive -> glTF default material: white, metallic 1, roughness 1; every
+    # other attribute keeps Material::MaterialAttributes' default
+    doc, blob, _ = _quad_document()
+    s = gltf.load(_write_gltf(tmp_path, doc, blob))
+    expect = [0, 0, 0, 1, 1, 1, 1.0, 0.0, 1.0, 1.0, 0, 0, 0, 0, 0, 0, 1.5, 0.0]
+    assert s.attributes[0].tolist() == expect
+    assert (s.slot_images[0] == -1).all()
+    # partial pbrMetallicRoughness: absent factors take the glTF defaults (1), not the struct's
+    mats = [{"pbrMetallicRoughness": {"baseColorFactor": [0.25, 0.5, 0.75, 0.3], "roughnessFactor": 0.125}}]
+    doc, blob, _ = _quad_document(materials=mats, material=0)
+    s = gltf.load(_write_gltf(tmp_path, doc, blob, name="b"))
+    a = s.attributes[0]
+    assert a[3:6].tolist() == [0.25, 0.5, 0.75] and a[8] == 1.0 and a[9] == 0.125
+    assert a[6] == 1.0 and a[7] == 0.0 and a[16] == 1.5  # specular, specularTint, refraction untouched
+
+
+def test_extension_mapping(tmp_path):
+    mats = [{
+        "emissiveFactor": [1.0, 0.5, 0.25],
+        "pbrMetallicRoughness": {"metallicFactor": 0.0, "roughnessFactor": 0.5},
+        "extensions": {
+            "KHR_materials_emissive_strength": {"emissiveStrength": 4.0},
+            "KHR_materials_specular": {"specularFactor": 0.5, "specularColorFactor": [0.0, 3.0, 4.0]},
+            "KHR_materials_sheen": {"sheenRoughnessFactor": 0.75, "sheenColorFactor": [1.0, 2.0, 2.0]},
+            "KHR_materials_clearcoat": {"clearcoatFactor": 0.875, "clearcoatRoughnessFactor": 0.0625},
+            "KHR_materials_ior": {"ior": 1.25},
+            "KHR_materials_transmission": {"transmissionFactor": 0.375},
+        }}]
+    doc, blob, _ = _quad_document(materials=mats, material=0)
+    a = gltf.load(_write_gltf(tmp_path, doc, blob)).attributes[0]
+    assert a[0:3].tolist() == [4.0, 2.0, 1.0]       # emission * strength
+    assert a[6] == 0.5 and a[7] == 5.0               # specular, |specularColorFactor|
+    assert a[8] == 0.0 and a[9] == 0.5
+    assert a[12] == 0.75 and a[13] == 3.0            # sheenRoughness, |sheenColorFactor|
+    assert a[14] == 0.875 and a[15] == 0.0625
+    assert a[16] == 1.25 and a[17] == 0.375
+    # KHR_materials_specular present with defaults: colour (1,1,1) -> tint = sqrt(3) in float
+    mats = [{"extensions": {"KHR_materials_specular": {"specularFactor": 0}}}]
+    doc, blob, _ = _quad_document(materials=mats, material=0)
+    a = gltf.load(_write_gltf(tmp_path, doc, blob, name="c")).attributes[0]
+    assert a[6] == 0.0 and a[7] == np.sqrt(np.float32(3.0))
+
+
+def test_generated_normals_and_errors(tmp_path):
+    doc, blob, (pos, _, _, _) = _quad_document(with_normals=False)
+    v, _ = gltf.load(_write_gltf(tmp_path, doc, blob)).submeshes[0]
+    assert np.array_equal(v[:, 3:6], np.tile(np.array([[0, 0, 1]], np.float32), (4, 1)))
+    # the reference's loader throws when a requested semantic is missing (ModelLoader.cpp:389-403)
+    doc, blob, _ = _quad_document(with_uv=False)
+    with pytest.raises(PtError, match="TEXCOORD_0") as e:
+        gltf.load(_write_gltf(tmp_path, doc, blob, name="nouv"))
+    assert e.value.code == -5
+    doc, blob, _ = _quad_document(mode=1)
+    with pytest.raises(PtError, match="triangle"):
+        gltf.load(_write_gltf(tmp_path, doc, blob, name="lines"))
+    with pytest.raises(PtError, match="cannot read"):
+        gltf.load(str(tmp_path / "missing.gltf"))
+    (tmp_path / "broken.gltf").write_text('{"asset": {"version": "2.0"}, "meshes": [')
+    with pytest.raises(PtError, match="JSON"):
+        gltf.load(str(tmp_path / "broken.gltf"))
+    doc, blob, _ = _quad_document()
+    doc["accessors"][3]["count"] = 600  # indices read past the view
+    with pytest.raises(PtError, match="past"):
+        gltf.load(_write_gltf(tmp_path, doc, blob, name="overrun"))
+
+
+def test_textures_slots_and_flip(tmp_path):
+    from PIL import Image
+    rgb = np.zeros((2, 3, 3), np.uint8)
+    rgb[0] = [[255, 0, 0], [0, 255, 0], [0, 0, 255]]  # top row of the picture
+    rgb[1] = [[10, 20, 30], [40, 50, 60], [70, 80, 90]]
+    buf = io.BytesIO()
+    Image.fromarray(rgb).save(buf, format="PNG")
+    (tmp_path / "base.png").write_bytes(buf.getvalue())
+    mats = [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}, "metallicRoughnessTexture": {"index": 0}},
+             "normalTexture": {"index": 1},
+             "extensions": {"KHR_materials_specular": {"specularColorTexture": {"index": 0}}}}]
+    images = [{"uri": "base.png"}, {"uri": "data:image/png;base64," + base64.b64encode(buf.getvalue()).decode()}]
+    textures = [{"source": 0}, {"source": 1}]
+    doc, blob, _ = _quad_document(materials=mats, material=0, images=images, textures=textures)
+    s = gltf.load(_write_gltf(tmp_path, doc, blob))
+    # emission, albedo, normal, specular, specularColor (same image as specular: the reference asks
+    # for texture 0 of the type in both slots), metallicRoughness, ...
+    assert s.slot_images[0].tolist() == [-1, 0, 1, 0, 0, 0, -1, -1, -1, -1, -1]
+    assert [k for k, _ in s.image_sources] == ["path", "bytes"]
+    mats176, tex = s.materials()
+    by_slot = {slot: (t, srgb) for slot, t, srgb in tex}
+    h = mats176[0]["handles"]
+    assert h[1] != h[5] and h[3] != h[4] and h[4] == h[5]  # sRGB / RGBA / RGB variants of image 0 are separate entries
+    albedo, srgb = by_slot[int(h[1])]
+    assert srgb and albedo.shape == (2, 3, 3) and np.array_equal(albedo, rgb[::-1])  # bottom row first
+    spec, srgb = by_slot[int(h[3])]
+    assert not srgb and spec.shape == (2, 3, 4) and (spec[..., 3] == 255).all()
+    normal, _ = by_slot[int(h[2])]
+    assert np.array_equal(normal, rgb[::-1])
+
+
+def test_committed_scene_fixtures():
+    s = gltf.GltfScene.from_npz(os.path.join(SCENES, "arealight.npz"))
+    assert len(s.submeshes) == 5 and s.triangle_count() == 8172
+    m = gltf.GltfScene.from_npz(os.path.join(SCENES, "mill.npz"))
+    assert len(m.submeshes) == 3 and m.triangle_count() == 16361 and len(m.image_sources) == 3
+    mats, tex = m.materials()
+    assert [t.shape for _, t, _ in tex] == [(256, 256, 3)] * 3
+    assert np.allclose(mats["roughness"], [0.0, 0.2181818187236786, 0.4018182158470154])
+    assert mats["metallic"].tolist() == [1.0, 0.0, 0.0]  # first material omits metallicFactor -> glTF default 1
