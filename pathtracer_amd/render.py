@@ -3,6 +3,7 @@
 
     python -m pathtracer_amd.render --scene BunnyClearcoat --width 512 --height 512 --spp 64 \
         --out bunny.png [--exr bunny.exr] [--pfm bunny.pfm] [--aov-prefix bunny_]
+    python -m pathtracer_amd.render --gltf Content/Models/Mill/Mill.gltf --eye 14 9 16 --look-at 0 5 0 ...
 
 FrameCount runs 1..spp (the reference application renders FrameCount 1..maxFrameCount-1,
 PathTracingApplication.cpp:85-88).  With --gpus N > 1 launch it under
@@ -19,7 +20,15 @@ import numpy as np
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--scene", default="BunnyDielectric",
-                    help="BunnyDielectric | BunnyMetallic | BunnyGlass | BunnyClearcoat | DragonGlass | TorusMixed")
+                    help="BunnyDielectric | BunnyMetallic | BunnyGlass | BunnyClearcoat | DragonGlass | TorusMixed | "
+                         "SphereField")
+    ap.add_argument("--gltf", default=None, action="append",
+                    help=".gltf / .glb file (or a tests/golden/scenes/*.npz fixture) to render instead of a recipe "
+                         "(repeatable: models are added in order)")
+    ap.add_argument("--max-texture-size", type=int, default=None, help="box-filter larger images down to this edge")
+    ap.add_argument("--eye", type=float, nargs=3, default=None, help="camera position (default -2.5 1 0)")
+    ap.add_argument("--look-at", type=float, nargs=3, default=None, help="camera target (default origin)")
+    ap.add_argument("--fovy", type=float, default=1.57, help="vertical field of view in radians (reference: 1.57)")
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--spp", type=int, default=49, help="samples per pixel (reference default: 49)")
@@ -49,7 +58,25 @@ def main(argv=None):
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    meshes, mats = scenes.flatten(scenes.recipe(args.scene))
+    textures = []
+    if args.gltf:
+        from . import gltf
+        meshes, mats = [], []
+        for path in args.gltf:
+            sc = gltf.GltfScene.from_npz(path) if path.endswith(".npz") else gltf.load(path)
+            m, t = sc.materials(args.max_texture_size)
+            shift = len(textures)  # texture-table entries of earlier files come first
+            for rec in m:
+                rec["handles"][rec["handles"] > 0] += shift
+            textures += [(slot + shift, texels, srgb) for slot, texels, srgb in t]
+            meshes += sc.submeshes
+            mats += list(m)
+        mats = np.array(mats, dtype=scenes.MATERIAL_DTYPE)
+        args.scene = ",".join(os.path.basename(x) for x in args.gltf)
+    elif args.scene == "SphereField":
+        meshes, mats = scenes.sphere_field()
+    else:
+        meshes, mats = scenes.flatten(scenes.recipe(args.scene))
     if args.hdri:
         path, w, h = args.hdri.rsplit(":", 2)
         hdri = np.fromfile(path, np.float32).reshape(int(h), int(w), 3)
@@ -59,12 +86,16 @@ def main(argv=None):
     sr = ShardedRenderer(args.width, args.height, local, rank, world)
     g = sr.renderer
     t0 = time.time()
+    for slot, texels, srgb in textures:
+        g.upload_texture(slot, texels, srgb)
     for (v, i), m in zip(meshes, mats):
         g.AddPathTracingModel(v, i, m)
     g.ProcessBuffers()  # flatten -> sweep-SAH BVH -> aligned buffers -> upload
     g.upload_environment(hdri)  # builds the importance-sampling cache on the host
     t_setup = time.time() - t0
     p = R.default_params(args.width, args.height)
+    if args.eye or args.look_at or args.fovy != 1.57:
+        R.set_camera(p, args.eye or (-2.5, 1.0, 0.0), args.look_at or (0.0, 0.0, 0.0), args.width, args.height, args.fovy)
     p.max_bounces = args.bounces
     p.aperture_size = args.aperture
     p.focal_length = args.focal_length

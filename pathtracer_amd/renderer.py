@@ -152,6 +152,22 @@ def default_params(width, height):
     return p
 
 
+def set_camera(params, eye, center, width, height, fovy=1.57, up=(0.0, 1.0, 0.0), z_near=0.01, z_far=1000.0):
+    """Fill the three camera matrices of `params` the way the reference's camera does
+    (Runtime/Camera/Camera.cpp:10-18: glm::lookAt, glm::perspective; PathTracingApplication.cpp:250:
+    glm::inverse of the projection)."""
+    lib = _l.load()
+    f = lambda v, n: (ctypes.c_float * n)(*[float(x) for x in v])
+    view, proj, inv = (ctypes.c_float * 16)(), (ctypes.c_float * 16)(), (ctypes.c_float * 16)()
+    lib.pt_look_at(f(eye, 3), f(center, 3), f(up, 3), view)
+    lib.pt_perspective(float(fovy), float(width) / float(height), float(z_near), float(z_far), proj)
+    lib.pt_inverse4(proj, inv)
+    params.view_matrix[:] = list(view)
+    params.proj_matrix[:] = list(proj)
+    params.inv_proj_matrix[:] = list(inv)
+    return params
+
+
 def build_bvh_sah(prims100, leaf_size=4):
     """prims100: (n, 25) float32 view of 100-B records. Returns (reordered prims, nodes (m, 10))."""
     p = np.ascontiguousarray(prims100, dtype=np.float32).copy()

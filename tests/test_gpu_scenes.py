@@ -22,27 +22,11 @@ pytestmark = pytest.mark.gpu
 SCENES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes")
 
 
-def _camera(p, eye, center, width, height, fovy=1.0):
-    view = np.zeros(16, np.float32)
-    proj = np.zeros(16, np.float32)
-    inv = np.zeros(16, np.float32)
-    lib = R._l.load()
-    f3 = lambda v: np.asarray(v, np.float32).ctypes.data_as(R._l.c_float_p)
-    up = np.array([0, 1, 0], np.float32)
-    e, c = np.asarray(eye, np.float32), np.asarray(center, np.float32)
-    lib.pt_look_at(f3(e), f3(c), f3(up), view.ctypes.data_as(R._l.c_float_p))
-    lib.pt_perspective(fovy, width / height, 0.01, 1000.0, proj.ctypes.data_as(R._l.c_float_p))
-    lib.pt_inverse4(proj.ctypes.data_as(R._l.c_float_p), inv.ctypes.data_as(R._l.c_float_p))
-    p.view_matrix[:] = view.tolist()
-    p.proj_matrix[:] = proj.tolist()
-    p.inv_proj_matrix[:] = inv.tolist()
-
-
 def _render_both(scene_tuple, textures, width, height, eye, center, bounces, frames, pipeline, what):
     o, g = _pair(scene_tuple, width, height, textures=textures, pipeline=pipeline)
     p = R.default_params(width, height)
     p.max_bounces = bounces
-    _camera(p, eye, center, width, height)
+    R.set_camera(p, eye, center, width, height, fovy=1.0)
     g.set_params(p)
     g.clear()
     g.dispatch(1, frames, 1, counted=True)
