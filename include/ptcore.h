@@ -245,7 +245,8 @@ int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, 
  * (0 = single-launch megakernel, the default; 1 = wavefront pipeline); 1: megakernel traversal-phase
  * exit threshold in 64ths of the live lanes (default 32); 2: wavefront refill threshold in idle
  * lanes (default 16); 3: wavefront iterations between read-backs of the live-ray count (default 2);
- * 4: traverse grid size in blocks (0 = sized from the occupancy query). */
+ * 4: traverse grid size in blocks (0 = sized from the occupancy query); 5: megakernel hit-shading
+ * threshold in 64ths of the live lanes (default 16): hits wait until that share of the wave holds one. */
 int pt_debug_set_tuning(pt_ctx* ctx, int key, int value);
 
 /* Profiling hook, not part of the drop-in surface (no counterpart in the reference): wave-level
@@ -253,8 +254,9 @@ int pt_debug_set_tuning(pt_ctx* ctx, int key, int value);
  * [0] traversal iterations, [1] lanes traversing in them, [2] iterations with a node step, [3] lanes
  * in node steps, [4] iterations with a triangle step, [5] lanes in triangle steps, [6] shading phases
  * that shaded something, [7] lanes shading a hit, [8] lanes shading a miss, [9] shading phases,
- * [10] lanes finishing a sample, [11] lanes starting a sample. */
-int pt_debug_get_profile(pt_ctx* ctx, uint64_t out12[12]);
+ * [10] lanes finishing a sample, [11] lanes starting a sample, [12] shader clock ticks waves spent in
+ * shading phases, [13] in traversal phases, [14] of [12] in the hit block, [15] of [12] in the miss block. */
+int pt_debug_get_profile(pt_ctx* ctx, uint64_t out16[16]);
 
 /* Test hook, not part of the drop-in surface (no counterpart in the reference): evaluates one
  * float32 building block of the kernels element-wise on the device so that tests can compare it

@@ -253,27 +253,30 @@ PT_DEV void startSample(const DevParams& P, unsigned px, unsigned py, PathState&
     ps.bounce = 0;
 }
 
-// One iteration of PathTrace's bounce loop (pathtracing.comp:25-140) around the closest-hit
-// result (prim, t, u, v) of the ray (ro, rd); prim < 0 is a miss.  Updates the path state and
-// returns the rays the bounce wants traced.  No ray at all means the path has ended.
-PT_DEV BounceRays shadeBounce(const DevParams& P, const DevScene& S, PathState& ps, v3 ro, v3 rd, int prim, float tHit,
-                              float uHit, float vHit)
+// The ray (.., rd) left the scene at bounce ps.bounce: environment radiance with MIS against the
+// BSDF sample that produced the ray (pathtracing.comp:36-52).  The path ends here.
+PT_DEV void shadeMiss(const DevParams& P, const DevScene& S, PathState& ps, v3 rd)
+{
+    float pdfLight = 0.0f;
+    v3 colorLight = evaluateHdri(S, P.envW, P.envH, P.hdriW, P.hdriH, rd, pdfLight);
+    float misWeight = 1.0f;
+    if (ps.bounce > 0u) {
+        float t = ps.pdfBsdf * ps.pdfBsdf;
+        misWeight = t / (pdfLight * pdfLight + t);
+    }
+    if (misWeight > 0.0f) ps.radiance = ps.radiance + misWeight * ps.throughput * colorLight * ps.f / ps.pdfBsdf;
+}
+
+// One iteration of PathTrace's bounce loop (pathtracing.comp:25-140) around the closest hit
+// (prim, t, u, v) of the ray (ro, rd).  Updates the path state and returns the rays the bounce
+// wants traced.  No ray at all means the path has ended.
+PT_DEV BounceRays shadeHit(const DevParams& P, const DevScene& S, PathState& ps, v3 ro, v3 rd, int prim, float tHit,
+                           float uHit, float vHit)
 {
     BounceRays out;
     out.hasShadow = false;
     out.hasExt = false;
     out.origin = out.shadowDir = out.extDir = out.pending = splat(0.0f);
-    if (prim < 0) {
-        float pdfLight = 0.0f;
-        v3 colorLight = evaluateHdri(S, P.envW, P.envH, P.hdriW, P.hdriH, rd, pdfLight);
-        float misWeight = 1.0f;
-        if (ps.bounce > 0u) {
-            float t = ps.pdfBsdf * ps.pdfBsdf;
-            misWeight = t / (pdfLight * pdfLight + t);
-        }
-        if (misWeight > 0.0f) ps.radiance = ps.radiance + misWeight * ps.throughput * colorLight * ps.f / ps.pdfBsdf;
-        return out;
-    }
     // hit attributes of the winning triangle (intersection.glsl:41-57)
     const float w = 1.0f - uHit - vHit;
     const v3 P0 = ro + rd * tHit;
@@ -338,6 +341,21 @@ PT_DEV BounceRays shadeBounce(const DevParams& P, const DevScene& S, PathState& 
         }
     }
     return out;
+}
+
+// Miss or hit in one call (prim < 0 is a miss), for callers that shade one ray per lane.
+PT_DEV BounceRays shadeBounce(const DevParams& P, const DevScene& S, PathState& ps, v3 ro, v3 rd, int prim, float tHit,
+                              float uHit, float vHit)
+{
+    if (prim < 0) {
+        shadeMiss(P, S, ps, rd);
+        BounceRays out;
+        out.hasShadow = false;
+        out.hasExt = false;
+        out.origin = out.shadowDir = out.extDir = out.pending = splat(0.0f);
+        return out;
+    }
+    return shadeHit(P, S, ps, ro, rd, prim, tHit, uHit, vHit);
 }
 
 PT_DEV float4 accumulate(float4 prev, v3 x, float weight, unsigned mode)
@@ -408,19 +426,39 @@ __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(
     v3 pending = splat(0.0f);  // NEE contribution, added if the shadow ray is unoccluded
     bool hasExt = false;
 
-    unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // wave-uniform, counting build only
+    unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // wave-uniform, counting build only
     for (;;) {
         // ================================================================ shading phase
+        unsigned long long tick = 0;
         if (COUNT) {
+            tick = __builtin_readcyclecounter();
             const int nShade = __popcll(__ballot(mode == kModeShade));
             prof[9]++;
             if (nShade) prof[6]++;
             prof[7] += (unsigned)__popcll(__ballot(mode == kModeShade && q.bestPrim >= 0));
             prof[8] += (unsigned)__popcll(__ballot(mode == kModeShade && q.bestPrim < 0));
         }
-        if (mode == kModeShade) {
-            if (q.bestPrim >= 0) nHits++;
-            const BounceRays br = shadeBounce(P, S, ps, q.ro, q.rd, q.bestPrim, q.bestT, q.bestU, q.bestV);
+        // a miss ends the path: environment radiance, then FINISH
+        if (mode == kModeShade && q.bestPrim < 0) {
+            shadeMiss(P, S, ps, q.rd);
+            mode = kModeFinish;
+        }
+        if (COUNT) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            prof[15] += now - tick;
+            prof[12] += now - tick;
+            tick = now;
+        }
+        // Hits are shaded once enough lanes hold one (the block is the most expensive of the phase
+        // and runs at the occupancy of the lanes that take part), or when too few other lanes
+        // are left to keep the traversal phase busy.
+        const int nHit = __popcll(__ballot(mode == kModeShade));
+        const int aliveNow = __popcll(__ballot(mode != kModeDone));
+        const bool doHit = nHit >= ((aliveNow * (int)P.hitMinNum + 63) >> 6) ||
+                           aliveNow - nHit < ((aliveNow * (int)P.travExitNum + 63) >> 6);
+        if (doHit && mode == kModeShade) {
+            nHits++;
+            const BounceRays br = shadeHit(P, S, ps, q.ro, q.rd, q.bestPrim, q.bestT, q.bestU, q.bestV);
             mode = kModeFinish;
             hasExt = false;
             if (br.hasShadow) {
@@ -435,6 +473,12 @@ __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(
                 beginQuery(q, P.rootRef, br.origin, br.extDir, false);
                 mode = kModeTrav;
             }
+        }
+        if (COUNT) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            prof[14] += now - tick;
+            prof[12] += now - tick;
+            tick = now;
         }
         if (COUNT) prof[10] += (unsigned)__popcll(__ballot(mode == kModeFinish));
         if (mode == kModeFinish) {
@@ -456,13 +500,18 @@ __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(
                 mode = kModeDone;
             }
         }
-        if (__ballot(mode == kModeTrav) == 0ull) break;
+        if (__ballot(mode == kModeTrav || mode == kModeShade) == 0ull) break;
         // Leave the traversal phase once fewer than `threshold` lanes are traversing; lanes that
-        // are done for good do not count against the wave.
-        const int alive = __popcll(__ballot(mode != kModeDone));
+        // are done for good or wait for the hit block do not count against the wave.
+        const int alive = __popcll(__ballot(mode != kModeDone && mode != kModeShade));
         const int threshold = (alive * (int)P.travExitNum + 63) >> 6;
 
         // ============================================================== traversal phase
+        if (COUNT) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            prof[12] += now - tick;
+            tick = now;
+        }
         for (;;) {
             if (COUNT) {
                 const unsigned long long tm = __ballot(mode == kModeTrav);
@@ -492,8 +541,12 @@ __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(
                     }
                 }
             }
-            if ((int)__popcll(__ballot(mode == kModeTrav)) < threshold) break;
+            // (no lane traversing ends the phase whatever the threshold: lanes waiting for the hit
+            // block can leave `alive`, and with it the threshold, at zero)
+            const int nTrav = __popcll(__ballot(mode == kModeTrav));
+            if (nTrav == 0 || nTrav < threshold) break;
         }
+        if (COUNT) prof[13] += __builtin_readcyclecounter() - tick;
     }
 
     // counters: wave-level reduction, one atomic per wave and counter
@@ -510,7 +563,7 @@ __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(
             atomicAdd(&counters->nodeVisits, (unsigned long long)sNodes);
             atomicAdd(&counters->triangleTests, (unsigned long long)sTris);
             atomicMax(&counters->maxStack, m);
-            for (int i = 0; i < 12; i++) atomicAdd(&counters->profile[i], prof[i]);
+            for (int i = 0; i < 16; i++) atomicAdd(&counters->profile[i], prof[i]);
         }
     }
 }

@@ -159,6 +159,7 @@ struct DevParams {
     uint32_t tilesX, tilesY;
     uint32_t travExitNum;  // megakernel: leave the traversal phase below this many 64ths of the live lanes
     uint32_t refillMin;    // wavefront: a wave refills from the ray queue once this many lanes are idle
+    uint32_t hitMinNum;    // megakernel: shade hits once this many 64ths of the live lanes hold one
 };
 
 struct DevCounters {
@@ -170,7 +171,7 @@ struct DevCounters {
     // step, [5] lanes in triangle steps, [6] shading phases with a hit/miss to shade, [7] lanes
     // shading a hit, [8] lanes shading a miss, [9] shading phases, [10] lanes finishing a sample,
     // [11] lanes starting a sample
-    unsigned long long profile[12];
+    unsigned long long profile[16];
 };
 
 }  // namespace ptcore

@@ -103,6 +103,7 @@ struct pt_ctx {
     int maxDepth = 0;
     uint32_t travExitNum = 32;  // of 64
     uint32_t refillMin = 16;
+    uint32_t hitMinNum = 16;
     int pipeline = 0;    // 0 = megakernel, 1 = wavefront
     int checkEvery = 2;  // wavefront: read the live-ray count back every this many iterations
     int traverseBlocks = 0;
@@ -371,6 +372,7 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
 
     P.travExitNum = c->travExitNum;
     P.refillMin = c->refillMin;
+    P.hitMinNum = c->hitMinNum;
     HIP_TRY(hipMemsetAsync(c->dCounters.ptr, 0, sizeof(DevCounters), c->stream));
     DevCounters* ctr = (DevCounters*)c->dCounters.ptr;
     Images img{imagePtr(c, 0), imagePtr(c, 1), imagePtr(c, 2)};
@@ -886,7 +888,8 @@ int pt_scene_bytes(pt_ctx* c, uint64_t* nodeBytes, uint64_t* triangleBytes, uint
 
 // Tuning hook.  key 0: pipeline (0 megakernel, 1 wavefront); 1: megakernel traversal-phase exit
 // threshold in 64ths of the live lanes; 2: wavefront refill threshold (idle lanes); 3: wavefront
-// iterations between read-backs of the live-ray count; 4: traverse grid size in blocks (0 = auto).
+// iterations between read-backs of the live-ray count; 4: traverse grid size in blocks (0 = auto);
+// 5: megakernel hit-shading threshold in 64ths of the live lanes.
 int pt_debug_set_tuning(pt_ctx* c, int key, int value)
 {
     if (!c) return fail(PT_ERR_INVALID, "null context");
@@ -911,20 +914,24 @@ int pt_debug_set_tuning(pt_ctx* c, int key, int value)
         if (value < 0 || value > 65535) return fail(PT_ERR_INVALID, "bad grid size");
         c->traverseBlocks = value;
         return PT_OK;
+    case 5:
+        if (value < 1 || value > 64) return fail(PT_ERR_INVALID, "hit threshold must be 1..64");
+        c->hitMinNum = (uint32_t)value;
+        return PT_OK;
     default: return fail(PT_ERR_INVALID, "unknown tuning key");
     }
 }
 
-// Profiling hook: the 12 wave-occupancy counters of the most recent pt_dispatch_counted() with the
+// Profiling hook: the 16 wave-occupancy counters of the most recent pt_dispatch_counted() with the
 // megakernel scheduler (see DevCounters::profile).
-int pt_debug_get_profile(pt_ctx* c, uint64_t out12[12])
+int pt_debug_get_profile(pt_ctx* c, uint64_t out16[16])
 {
-    if (!c || !out12) return fail(PT_ERR_INVALID, "null argument");
+    if (!c || !out16) return fail(PT_ERR_INVALID, "null argument");
     DeviceGuard guard(c->device);
     DevCounters h{};
     HIP_TRY(hipMemcpyAsync(&h, c->dCounters.ptr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 12; i++) out12[i] = h.profile[i];
+    for (int i = 0; i < 16; i++) out16[i] = h.profile[i];
     return PT_OK;
 }
 

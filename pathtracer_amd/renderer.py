@@ -106,15 +106,15 @@ class Renderer:
         fn = self._lib.pt_dispatch_counted if counted else self._lib.pt_dispatch
         check(fn(self._h, int(frame_first), int(frame_count), int(frame_stride)))
 
-    TUNING_KEYS = {"pipeline": 0, "trav_exit": 1, "refill_min": 2, "check_every": 3, "traverse_blocks": 4}
+    TUNING_KEYS = {"pipeline": 0, "trav_exit": 1, "refill_min": 2, "check_every": 3, "traverse_blocks": 4, "hit_min": 5}
 
     def set_tuning(self, **kw):
-        """pipeline=0|1 (megakernel|wavefront), trav_exit, refill_min, check_every, traverse_blocks."""
+        """pipeline=0|1 (megakernel|wavefront), trav_exit, refill_min, check_every, traverse_blocks, hit_min."""
         for k, v in kw.items():
             check(self._lib.pt_debug_set_tuning(self._h, self.TUNING_KEYS[k], int(v)))
 
     def profile(self):
-        out = (ctypes.c_uint64 * 12)()
+        out = (ctypes.c_uint64 * 16)()
         check(self._lib.pt_debug_get_profile(self._h, out))
         return list(out)
 

@@ -32,3 +32,6 @@ print(f"  with triangle step {pr[4]} ({pr[4] / pr[0]:.2%})  avg lanes {pr[5] / m
 print(f"shading phases {pr[9]}  shading something {pr[6]}  hit lanes/phase {pr[7] / max(pr[6], 1):.1f}  miss lanes/phase {pr[8] / max(pr[6], 1):.1f}")
 print(f"  finish lanes/phase {pr[10] / pr[9]:.1f}  new-sample lanes/phase {pr[11] / pr[9]:.1f}")
 print(f"  traversal iterations per shading phase {pr[0] / pr[9]:.1f}")
+print(f"  wave clock ticks: shading phases {pr[12]} ({pr[12] / max(pr[12] + pr[13], 1):.1%}), traversal phases {pr[13]}; "
+      f"per shading phase {pr[12] / pr[9]:.0f}, per traversal iteration {pr[13] / pr[0]:.0f}")
+print(f"  of the shading ticks: miss block {pr[15] / pr[12]:.1%}, hit block {pr[14] / pr[12]:.1%}, finish + new {1 - (pr[14] + pr[15]) / pr[12]:.1%}")
