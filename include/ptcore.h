@@ -234,6 +234,11 @@ int pt_synchronize(pt_ctx* ctx);
 /* glGetTexImage(GL_RGBA, GL_FLOAT) (PathTracingRenderPass.cpp:89-99 reads GL_RGB): copies
  * width*height*4 floats to host memory; synchronises the stream. */
 int pt_read_image(pt_ctx* ctx, int which, float* rgba_out);
+/* The same read-back in the reference's own layout: glGetTexImage(GL_RGB, GL_FLOAT) into
+ * glm::vec3[width*height] (PathTracingRenderPass.cpp:89-99), which is also the Float3 row-major
+ * buffer the reference hands to its denoiser for colour, albedo and normal (:101-155).  Copies
+ * width*height*3 floats; synchronises the stream. */
+int pt_read_image_rgb(pt_ctx* ctx, int which, float* rgb_out);
 int pt_get_stats(pt_ctx* ctx, pt_stats* out);
 /* Milliseconds spent by the device in the most recent dispatch (HIP events on the context's
  * stream); synchronises. */

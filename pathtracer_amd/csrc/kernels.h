@@ -890,6 +890,29 @@ __global__ void scaleImagesKernel(float4* a, float4* b, float4* c, size_t n, flo
     }
 }
 
+// RGBA32F image -> tightly packed RGB32F (the layout glGetTexImage(GL_RGB, GL_FLOAT) returns and
+// a denoiser's Float3 input expects).  Four texels per thread: 3 x 16-B stores for 4 x 16-B loads.
+__global__ void packRgbKernel(const float4* __restrict__ in, float* __restrict__ out, size_t texels)
+{
+    const size_t quad = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t first = quad * 4;
+    if (first >= texels) return;
+    if (first + 4 <= texels) {
+        const float4 a = in[first], b = in[first + 1], c = in[first + 2], d = in[first + 3];
+        float4* o = reinterpret_cast<float4*>(out + first * 3);
+        o[0] = make_float4(a.x, a.y, a.z, b.x);
+        o[1] = make_float4(b.y, b.z, c.x, c.y);
+        o[2] = make_float4(c.z, d.x, d.y, d.z);
+    } else {
+        for (size_t i = first; i < texels; i++) {
+            const float4 a = in[i];
+            out[i * 3] = a.x;
+            out[i * 3 + 1] = a.y;
+            out[i * 3 + 2] = a.z;
+        }
+    }
+}
+
 // Element-wise evaluation of the float32 building blocks, so tests can compare them bit for bit
 // with a CPU evaluation of the same operation sequences.
 __global__ void evalMathKernel(int fn, const float* a, const float* b, float* out, size_t n)

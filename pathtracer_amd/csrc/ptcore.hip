@@ -98,6 +98,7 @@ struct pt_ctx {
     DeviceBuffer dNodes, dTriangles, dShading, dMaterials, dTextures, dTexels, dSrgbLut, dEnvColorPdf, dEnvSample;
     DeviceBuffer dImages[3];
     DeviceBuffer dCounters;
+    DeviceBuffer dRgbStaging;  // pt_read_image_rgb
     float4* bound[3] = {nullptr, nullptr, nullptr};
     int32_t rootRef = 0;
     int maxDepth = 0;
@@ -450,7 +451,7 @@ void pt_destroy(pt_ctx* c)
     if (!c) return;
     DeviceGuard guard(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DeviceBuffer* all[] = {&c->dNodes, &c->dTriangles, &c->dShading, &c->dMaterials, &c->dTextures, &c->dTexels,
+    DeviceBuffer* all[] = {&c->dRgbStaging, &c->dNodes, &c->dTriangles, &c->dShading, &c->dMaterials, &c->dTextures, &c->dTexels,
                            &c->dSrgbLut, &c->dEnvColorPdf, &c->dEnvSample, &c->dImages[0], &c->dImages[1],
                            &c->dImages[2], &c->dCounters};
     for (DeviceBuffer* b : all) b->release();
@@ -845,6 +846,22 @@ int pt_read_image(pt_ctx* c, int which, float* rgbaOut)
     DeviceGuard guard(c->device);
     const size_t imageBytes = (size_t)c->width * c->height * sizeof(float4);
     HIP_TRY(hipMemcpyAsync(rgbaOut, imagePtr(c, which), imageBytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_read_image_rgb(pt_ctx* c, int which, float* rgbOut)
+{
+    if (!c || !rgbOut) return fail(PT_ERR_INVALID, "null argument");
+    if (which < 0 || which > 2) return fail(PT_ERR_INVALID, "image index must be 0..2");
+    DeviceGuard guard(c->device);
+    const size_t texels = (size_t)c->width * c->height;
+    HIP_TRY(c->dRgbStaging.ensure(texels * 3 * sizeof(float)));
+    const size_t quads = (texels + 3) / 4;
+    hipLaunchKernelGGL(packRgbKernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, c->stream, imagePtr(c, which),
+                       (float*)c->dRgbStaging.ptr, texels);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rgbOut, c->dRgbStaging.ptr, texels * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PT_OK;
 }

@@ -129,6 +129,12 @@ class Renderer:
         check(self._lib.pt_read_image(self._h, int(which), _ptr(out)))
         return out
 
+    def read_image_rgb(self, which):
+        """(height, width, 3) float32: the layout the reference reads back for its denoiser."""
+        out = np.empty((self.height, self.width, 3), np.float32)
+        check(self._lib.pt_read_image_rgb(self._h, int(which), _ptr(out)))
+        return out
+
     def stats(self):
         s = Stats()
         check(self._lib.pt_get_stats(self._h, ctypes.byref(s)))

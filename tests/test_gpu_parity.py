@@ -317,6 +317,20 @@ def test_bind_images_renders_into_caller_memory():
         g.bind_images(bufs[0].data_ptr(), 0, 0)
 
 
+def test_read_image_rgb_is_the_rgba_image_without_alpha():
+    # 37 x 29 = 1073 texels: not a multiple of four, so the packed copy's tail path runs too
+    for width, height in ((37, 29), (64, 32)):
+        o, g = _pair("TorusMixed", width, height)
+        g.set_params(R.default_params(width, height))
+        g.clear()
+        g.dispatch(1, 2, 1)
+        for which in range(3):
+            rgba = g.read_image(which)
+            rgb = g.read_image_rgb(which)
+            assert rgb.shape == (height, width, 3)
+            assert np.array_equal(rgb.view(np.uint32), rgba[..., :3].view(np.uint32).reshape(height, width, 3))
+
+
 def test_error_behaviour():
     g = R.Renderer(32, 32)
     with pytest.raises(L.PtError) as e:
