@@ -177,6 +177,21 @@ int pt_align_primitives(const void* prims100, size_t count, void* prims112_out);
 /* CalculateHdriCache (PathTracingRenderer.cpp:803-901): cache_out = w*h*3 floats. */
 int pt_calculate_hdri_cache(const float* hdri_rgb, int width, int height, float* cache_out);
 
+/* BVH construction on the GPU (no counterpart in the reference): a linear BVH over Morton-sorted
+ * triangle centroids, leaves of at most 4 triangles, for scenes where BVH::BuildBvhWithSah's
+ * O(n log^2 n) sweep takes minutes.  The tree differs from the one BVH.cpp builds (lower SAH quality),
+ * images differ from the reference's only where distances tie exactly.  prims112: `count` unsorted
+ * BvhPrimitiveAlign records (host memory); the call uploads them, builds and installs the geometry
+ * in place of pt_upload_nodes + pt_upload_primitives.  PT_ERR_SCENE if the tree comes out deeper
+ * than the traversal stack (64 levels). */
+int pt_build_bvh_device(pt_ctx* ctx, const void* prims112, size_t count);
+/* pt_process_buffers with the GPU builder in place of BuildBvhWithSah. */
+int pt_process_buffers_device(pt_ctx* ctx);
+/* The device-built tree in the reference's layouts (BvhNodeAlign incl. dummy node 0, root = node 1;
+ * BvhPrimitiveAlign in leaf order).  Pass NULL output pointers to query the counts. */
+int pt_download_bvh(pt_ctx* ctx, void* nodes48_out, size_t node_capacity, size_t* node_count_out, void* prims112_out,
+                    size_t prim_capacity, size_t* prim_count_out);
+
 /* glTF 2.0 / GLB scene reader: what ModelLoader::Load (ModelLoader.cpp:83-121) hands to
  * PathTracingRenderer::AddPathTracingModel, without assimp.  One sub-mesh per mesh primitive, in file
  * order; node transforms are ignored as in the reference; vertices are {pos, nor, uv} with V flipped

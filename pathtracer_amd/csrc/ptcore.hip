@@ -17,6 +17,9 @@
 #include "../../include/ptcore.h"
 #include "host.h"
 #include "kernels.h"
+#include "lbvh.h"
+
+#include <hipcub/hipcub.hpp>
 
 using namespace ptcore;
 
@@ -99,6 +102,12 @@ struct pt_ctx {
     DeviceBuffer dImages[3];
     DeviceBuffer dCounters;
     DeviceBuffer dRgbStaging;  // pt_read_image_rgb
+    // geometry built on the device (pt_build_bvh_device): the tree in the reference's layouts, kept for
+    // pt_download_bvh; dNodes / dTriangles / dShading are filled by the builder itself
+    DeviceBuffer dRefNodes, dRefPrims;
+    bool deviceGeometry = false;
+    size_t deviceNodeCount = 0, devicePrimCount = 0;
+    uint32_t deviceMaxMeshIndex = 0;
     float4* bound[3] = {nullptr, nullptr, nullptr};
     int32_t rootRef = 0;
     int maxDepth = 0;
@@ -135,12 +144,16 @@ float4* imagePtr(pt_ctx* c, int which) { return c->bound[which] ? c->bound[which
 
 int syncScene(pt_ctx* c)
 {
-    if (c->nodes.empty() || c->prims.empty()) return fail(PT_ERR_STATE, "no BVH nodes / primitives uploaded");
+    if (!c->deviceGeometry && (c->nodes.empty() || c->prims.empty()))
+        return fail(PT_ERR_STATE, "no BVH nodes / primitives uploaded");
     if (c->materials.empty()) return fail(PT_ERR_STATE, "no materials uploaded");
     if (c->envW == 0) return fail(PT_ERR_STATE, "no environment uploaded");
     if (!c->haveParams) return fail(PT_ERR_STATE, "pt_set_params has not been called");
 
-    if (c->geometryDirty) {
+    if (c->deviceGeometry && c->deviceMaxMeshIndex >= c->materials.size())
+        return fail(PT_ERR_SCENE, "a primitive has meshIndex " + std::to_string(c->deviceMaxMeshIndex) + " but only " +
+                                      std::to_string(c->materials.size()) + " materials are uploaded");
+    if (c->geometryDirty && !c->deviceGeometry) {
         PackedScene packed;
         std::string err = PackScene(c->nodes.data(), c->nodes.size(), c->prims.data(), c->prims.size(),
                                     c->materials.size(), packed);
@@ -451,7 +464,7 @@ void pt_destroy(pt_ctx* c)
     if (!c) return;
     DeviceGuard guard(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DeviceBuffer* all[] = {&c->dRgbStaging, &c->dNodes, &c->dTriangles, &c->dShading, &c->dMaterials, &c->dTextures, &c->dTexels,
+    DeviceBuffer* all[] = {&c->dRefNodes, &c->dRefPrims, &c->dRgbStaging, &c->dNodes, &c->dTriangles, &c->dShading, &c->dMaterials, &c->dTextures, &c->dTexels,
                            &c->dSrgbLut, &c->dEnvColorPdf, &c->dEnvSample, &c->dImages[0], &c->dImages[1],
                            &c->dImages[2], &c->dCounters};
     for (DeviceBuffer* b : all) b->release();
@@ -504,6 +517,7 @@ int pt_upload_nodes(pt_ctx* c, const void* nodes48, size_t count)
     const RefNodeAlign* p = (const RefNodeAlign*)nodes48;
     c->nodes.assign(p, p + count);
     c->geometryDirty = true;
+    c->deviceGeometry = false;
     return PT_OK;
 }
 
@@ -514,6 +528,7 @@ int pt_upload_primitives(pt_ctx* c, const void* prims112, size_t count)
     const RefPrimitiveAlign* p = (const RefPrimitiveAlign*)prims112;
     c->prims.assign(p, p + count);
     c->geometryDirty = true;
+    c->deviceGeometry = false;
     return PT_OK;
 }
 
@@ -982,6 +997,196 @@ int pt_debug_eval_math(int device, int fn, const float* a, const float* b, float
     db.release();
     dout.release();
     return rc;
+}
+
+}  // extern "C"
+
+namespace {
+
+// Scratch of one device build, released when the build returns.
+struct LbvhScratch {
+    DeviceBuffer in, keys, keysSorted, values, order, sortTemp, parent, left, right, first, last, box, height, visits, emit,
+        kept, emitAt, keptAt, scanTemp, bounds;
+    ~LbvhScratch()
+    {
+        DeviceBuffer* all[] = {&in, &keys, &keysSorted, &values, &order, &sortTemp, &parent, &left, &right, &first, &last,
+                               &box, &height, &visits, &emit, &kept, &emitAt, &keptAt, &scanTemp, &bounds};
+        for (DeviceBuffer* b : all) b->release();
+    }
+};
+
+int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count)
+{
+    if (count == 0) return fail(PT_ERR_INVALID, "no primitives");
+    if (count >= (1u << 27)) return fail(PT_ERR_INVALID, "too many primitives (limit 2^27)");
+    DeviceGuard guard(c->device);
+    const int n = (int)count;
+    const unsigned int un = (unsigned int)count;
+    const size_t internal = count > 1 ? count - 1 : 1;
+    LbvhScratch w;
+    HIP_TRY(w.in.ensure(count * sizeof(RefPrimitiveAlign)));
+    HIP_TRY(w.keys.ensure(count * 8));
+    HIP_TRY(w.keysSorted.ensure(count * 8));
+    HIP_TRY(w.values.ensure(count * 4));
+    HIP_TRY(w.order.ensure(count * 4));
+    HIP_TRY(w.parent.ensure((2 * count) * 4));
+    HIP_TRY(w.left.ensure(internal * 4));
+    HIP_TRY(w.right.ensure(internal * 4));
+    HIP_TRY(w.first.ensure(internal * 4));
+    HIP_TRY(w.last.ensure(internal * 4));
+    HIP_TRY(w.box.ensure((2 * count) * 6 * 4));
+    HIP_TRY(w.height.ensure(internal * 4));
+    HIP_TRY(w.visits.ensure(internal * 4));
+    HIP_TRY(w.emit.ensure(internal * 4));
+    HIP_TRY(w.kept.ensure(internal * 4));
+    HIP_TRY(w.emitAt.ensure(internal * 4));
+    HIP_TRY(w.keptAt.ensure(internal * 4));
+    HIP_TRY(w.bounds.ensure(sizeof(LbvhBounds)));
+    HIP_TRY(c->dRefPrims.ensure(count * sizeof(RefPrimitiveAlign)));
+    HIP_TRY(c->dTriangles.ensure(count * sizeof(DevTriangle)));
+    HIP_TRY(c->dShading.ensure(count * sizeof(DevShading)));
+
+    hipStream_t st = c->stream;
+    const dim3 block(256), gridPrims((un + 255u) / 256u), gridNodes((unsigned int)((internal + 255) / 256));
+    const RefPrimitiveAlign* dIn = (const RefPrimitiveAlign*)w.in.ptr;
+    HIP_TRY(hipMemcpyAsync(w.in.ptr, hostPrims, count * sizeof(RefPrimitiveAlign), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(lbvhInitBoundsKernel, dim3(1), dim3(64), 0, st, (LbvhBounds*)w.bounds.ptr);
+    hipLaunchKernelGGL(lbvhBoundsKernel, gridPrims, block, 0, st, dIn, un, (LbvhBounds*)w.bounds.ptr);
+    hipLaunchKernelGGL(lbvhMortonKernel, gridPrims, block, 0, st, dIn, un, (const LbvhBounds*)w.bounds.ptr,
+                       (unsigned long long*)w.keys.ptr, (unsigned int*)w.values.ptr);
+    HIP_TRY(hipGetLastError());
+    size_t tempBytes = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, (const unsigned long long*)w.keys.ptr,
+                                               (unsigned long long*)w.keysSorted.ptr, (const unsigned int*)w.values.ptr,
+                                               (unsigned int*)w.order.ptr, n, 0, 63, st));
+    HIP_TRY(w.sortTemp.ensure(tempBytes));
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(w.sortTemp.ptr, tempBytes, (const unsigned long long*)w.keys.ptr,
+                                               (unsigned long long*)w.keysSorted.ptr, (const unsigned int*)w.values.ptr,
+                                               (unsigned int*)w.order.ptr, n, 0, 63, st));
+
+    LbvhTree T{(int*)w.parent.ptr, (int*)w.left.ptr,   (int*)w.right.ptr,  (int*)w.first.ptr,
+               (int*)w.last.ptr,   (float*)w.box.ptr,  (int*)w.height.ptr, (unsigned int*)w.visits.ptr};
+    HIP_TRY(hipMemsetAsync(w.visits.ptr, 0, internal * 4, st));
+    HIP_TRY(hipMemsetAsync(w.height.ptr, 0, internal * 4, st));
+    if (n > 1) hipLaunchKernelGGL(lbvhTreeKernel, gridNodes, block, 0, st, (const unsigned long long*)w.keysSorted.ptr, n, T);
+    hipLaunchKernelGGL(lbvhFitKernel, gridPrims, block, 0, st, dIn, (const unsigned int*)w.order.ptr, n, T);
+    hipLaunchKernelGGL(lbvhEmitTrianglesKernel, gridPrims, block, 0, st, dIn, (const unsigned int*)w.order.ptr, un,
+                       (RefPrimitiveAlign*)c->dRefPrims.ptr, (DevTriangle*)c->dTriangles.ptr, (DevShading*)c->dShading.ptr);
+    HIP_TRY(hipGetLastError());
+
+    size_t refNodeCount = 2, devNodeCount = 1;
+    int height = 0;
+    LbvhBounds hb{};
+    if (n > kLbvhLeafMax) {
+        hipLaunchKernelGGL(lbvhCountKernel, gridNodes, block, 0, st, n, T, (unsigned int*)w.emit.ptr, (unsigned int*)w.kept.ptr);
+        HIP_TRY(hipGetLastError());
+        size_t scanBytes = 0;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes, (const unsigned int*)w.emit.ptr, (unsigned int*)w.emitAt.ptr,
+                                                 n - 1, st));
+        HIP_TRY(w.scanTemp.ensure(scanBytes));
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(w.scanTemp.ptr, scanBytes, (const unsigned int*)w.emit.ptr,
+                                                 (unsigned int*)w.emitAt.ptr, n - 1, st));
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(w.scanTemp.ptr, scanBytes, (const unsigned int*)w.kept.ptr,
+                                                 (unsigned int*)w.keptAt.ptr, n - 1, st));
+        unsigned int tail[4] = {0, 0, 0, 0};  // last elements of emit, emitAt, kept, keptAt
+        HIP_TRY(hipMemcpyAsync(&tail[0], (unsigned int*)w.emit.ptr + (n - 2), 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&tail[1], (unsigned int*)w.emitAt.ptr + (n - 2), 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&tail[2], (unsigned int*)w.kept.ptr + (n - 2), 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&tail[3], (unsigned int*)w.keptAt.ptr + (n - 2), 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&height, w.height.ptr, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&hb, w.bounds.ptr, sizeof(hb), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        refNodeCount = 1 + (size_t)tail[0] + tail[1];
+        devNodeCount = 1 + (size_t)tail[2] + tail[3];
+        if (height > 64)
+            return fail(PT_ERR_SCENE, "the device-built BVH is " + std::to_string(height) +
+                                          " levels deep; the traversal stack holds 64 (use the host builder)");
+        HIP_TRY(c->dRefNodes.ensure(refNodeCount * sizeof(RefNodeAlign)));
+        HIP_TRY(c->dNodes.ensure(devNodeCount * sizeof(DevNode)));
+        HIP_TRY(hipMemsetAsync(c->dRefNodes.ptr, 0, sizeof(RefNodeAlign), st));
+        HIP_TRY(hipMemsetAsync(c->dNodes.ptr, 0, sizeof(DevNode), st));
+        hipLaunchKernelGGL(lbvhEmitNodesKernel, gridNodes, block, 0, st, n, T, (const unsigned int*)w.emitAt.ptr,
+                           (const unsigned int*)w.keptAt.ptr, (const unsigned int*)w.kept.ptr, (RefNodeAlign*)c->dRefNodes.ptr,
+                           (DevNode*)c->dNodes.ptr);
+        HIP_TRY(hipGetLastError());
+        c->rootRef = 1;
+    } else {
+        HIP_TRY(c->dRefNodes.ensure(2 * sizeof(RefNodeAlign)));
+        HIP_TRY(c->dNodes.ensure(sizeof(DevNode)));
+        HIP_TRY(hipMemsetAsync(c->dRefNodes.ptr, 0, 2 * sizeof(RefNodeAlign), st));
+        hipLaunchKernelGGL(lbvhEmitRootLeafKernel, dim3(1), dim3(64), 0, st, n, T, (RefNodeAlign*)c->dRefNodes.ptr,
+                           (DevNode*)c->dNodes.ptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&hb, w.bounds.ptr, sizeof(hb), hipMemcpyDeviceToHost, st));
+        c->rootRef = ~(int32_t)((0u << 3) | (unsigned int)(n - 1));
+    }
+    HIP_TRY(hipStreamSynchronize(st));  // the scratch buffers die with this scope
+    c->maxDepth = height;
+    c->deviceGeometry = true;
+    c->geometryDirty = false;
+    c->nodes.clear();
+    c->prims.clear();
+    c->deviceNodeCount = refNodeCount;
+    c->devicePrimCount = count;
+    c->deviceMaxMeshIndex = hb.maxMeshIndex;
+    c->nodeBytes = devNodeCount * sizeof(DevNode);
+    c->triangleBytes = count * sizeof(DevTriangle);
+    c->shadingBytes = count * sizeof(DevShading);
+    return PT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pt_build_bvh_device(pt_ctx* c, const void* prims112, size_t count)
+{
+    if (!c || !prims112) return fail(PT_ERR_INVALID, "null argument");
+    return buildLbvh(c, (const RefPrimitiveAlign*)prims112, count);
+}
+
+int pt_process_buffers_device(pt_ctx* c)
+{
+    if (!c) return fail(PT_ERR_INVALID, "null context");
+    if (c->models.empty()) return fail(PT_ERR_STATE, "no models added");
+    size_t triangles = 0;
+    for (const PendingModel& m : c->models) triangles += m.indices.size() / 3;
+    if (triangles == 0) return fail(PT_ERR_STATE, "models contain no triangles");
+    std::vector<RefPrimitive> soup(triangles);
+    std::vector<RefMaterialAlign> mats;
+    size_t at = 0;
+    uint32_t meshIndex = 0;
+    for (const PendingModel& m : c->models) {
+        AssemblePrimitives(m.vertices.data(), m.indices.data(), m.indices.size(), 4, meshIndex, soup.data() + at);
+        at += m.indices.size() / 3;
+        mats.push_back(m.material);
+        meshIndex++;
+    }
+    std::vector<RefPrimitiveAlign> aligned(soup.size());
+    AlignPrimitives(soup.data(), soup.size(), aligned.data());
+    int rc = pt_upload_materials(c, mats.data(), mats.size());
+    if (rc != PT_OK) return rc;
+    return buildLbvh(c, aligned.data(), aligned.size());
+}
+
+int pt_download_bvh(pt_ctx* c, void* nodes48Out, size_t nodeCapacity, size_t* nodeCountOut, void* prims112Out,
+                    size_t primCapacity, size_t* primCountOut)
+{
+    if (!c || !nodeCountOut || !primCountOut) return fail(PT_ERR_INVALID, "null argument");
+    if (!c->deviceGeometry) return fail(PT_ERR_STATE, "the current geometry was not built on the device");
+    *nodeCountOut = c->deviceNodeCount;
+    *primCountOut = c->devicePrimCount;
+    if (!nodes48Out && !prims112Out) return PT_OK;  // size query
+    if (!nodes48Out || !prims112Out) return fail(PT_ERR_INVALID, "null output buffer");
+    if (nodeCapacity < c->deviceNodeCount || primCapacity < c->devicePrimCount)
+        return fail(PT_ERR_INVALID, "output capacity too small: need " + std::to_string(c->deviceNodeCount) + " nodes and " +
+                                        std::to_string(c->devicePrimCount) + " primitives");
+    DeviceGuard guard(c->device);
+    HIP_TRY(hipMemcpyAsync(nodes48Out, c->dRefNodes.ptr, c->deviceNodeCount * sizeof(RefNodeAlign), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(prims112Out, c->dRefPrims.ptr, c->devicePrimCount * sizeof(RefPrimitiveAlign), hipMemcpyDeviceToHost,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PT_OK;
 }
 
 }  // extern "C"

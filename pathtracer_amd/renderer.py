@@ -95,6 +95,25 @@ class Renderer:
     def ProcessBuffers(self):
         check(self._lib.pt_process_buffers(self._h))
 
+    def ProcessBuffersDevice(self):
+        """ProcessBuffers with the BVH built on the GPU (Morton-code linear BVH) instead of the sweep SAH."""
+        check(self._lib.pt_process_buffers_device(self._h))
+
+    def build_bvh_device(self, prims112):
+        a = np.ascontiguousarray(prims112)
+        assert a.nbytes % 112 == 0
+        check(self._lib.pt_build_bvh_device(self._h, _ptr(a), a.nbytes // 112))
+
+    def download_bvh(self):
+        """-> (nodes48 (n, 12) float32 view, prims112 (m, 28) float32 view) of the device-built tree."""
+        nn, npr = ctypes.c_size_t(), ctypes.c_size_t()
+        check(self._lib.pt_download_bvh(self._h, None, 0, ctypes.byref(nn), None, 0, ctypes.byref(npr)))
+        nodes = np.zeros((nn.value, 12), np.float32)
+        prims = np.zeros((npr.value, 28), np.float32)
+        check(self._lib.pt_download_bvh(self._h, _ptr(nodes), nn.value, ctypes.byref(nn), _ptr(prims), npr.value,
+                                        ctypes.byref(npr)))
+        return nodes, prims
+
     # ------------------------------------------------------------------- per frame
     def set_params(self, params):
         check(self._lib.pt_set_params(self._h, ctypes.byref(params)))

@@ -86,3 +86,24 @@ def test_bunny_subdivided_half_million_triangles():
     mats = np.array([m for _, m in scenes.recipe("DragonGlass")], dtype=scenes.MATERIAL_DTYPE)
     _render_both(built_meshes(meshes, mats), None, 128, 96, (-2.5, 1.0, 0.0), (0.0, 0.0, 0.0), 8, 1, 0,
                  "subdivided bunny 128x96")
+
+
+def test_converged_images_agree_within_rmse():
+    # Converged-image check with a stated tolerance: 256 spp rendered by the GPU from FrameCount
+    # 1..256 against 256 spp rendered by the oracle from the DISJOINT FrameCount 257..512 (other
+    # random streams entirely).  Both estimate the same image, so they may differ only by Monte-Carlo
+    # noise: relative RMSE of the tone-mapped radiance below 2 %, mean within 0.5 %.
+    from pathtracer_amd import image_io
+    width, height, n = 96, 96, 256
+    o, g = _pair("BunnyClearcoat", width, height, env=(512, 256))
+    p = R.default_params(width, height)
+    g.set_params(p)
+    g.clear()
+    g.dispatch(1, n, 1)
+    gpu = g.read_image(0)[..., :3]
+    p.accumulate_mode = 1  # sums: the oracle's frames do not start at 1, a running mean would weight them wrongly
+    cpu = o.render(p, width, height, n + 1, n, 1)[0][..., :3] / np.float32(n)
+    a, b = image_io.tonemap(gpu, 1.0).astype(np.float64), image_io.tonemap(cpu, 1.0).astype(np.float64)
+    rmse = np.sqrt(np.mean((a - b) ** 2)) / max(np.mean(b), 1e-9)
+    assert rmse < 0.02, rmse
+    assert abs(gpu.mean() / cpu.mean() - 1.0) < 0.005
