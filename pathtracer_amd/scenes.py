@@ -144,6 +144,35 @@ def sphere_field(grid=8, spacing=2.5, radius=1.0, seed=1, levels=1):
     return meshes, np.array(mats, dtype=MATERIAL_DTYPE)
 
 
+def instanced_bunnies(copies, seed=1):
+    """`copies` bunnies on a jittered square grid (offsets from a 64-bit LCG seeded with `seed`)
+    over one floor scaled to fit, every copy flattened into the soup: the reference has no
+    instancing.  139 copies are 20 M triangles.  -> (list of (vertices, indices)), materials
+    (DragonGlass recipe: all bunnies share material row 0, the floor is row 1), grid side."""
+    bv, bi = load_ptm("bunny")
+    fv, fi = load_ptm("floor")
+    side = int(np.ceil(np.sqrt(copies)))
+    state = int(seed)
+    vs, is_, k = [], [], 0
+    for gz in range(side):
+        for gx in range(side):
+            if k == copies:
+                break
+            state = (state * 6364136223846793005 + 1442695040888963407) & (2 ** 64 - 1)
+            jx = (((state >> 40) & 0xFFFF) / 65535.0 - 0.5) * 0.6
+            jz = (((state >> 20) & 0xFFFF) / 65535.0 - 0.5) * 0.6
+            v = bv.copy()
+            v[:, 0] += np.float32((gx - 0.5 * (side - 1)) * 2.2 + jx)
+            v[:, 2] += np.float32((gz - 0.5 * (side - 1)) * 2.2 + jz)
+            vs.append(v)
+            is_.append(bi + np.uint32(k * bv.shape[0]))
+            k += 1
+    f = fv.copy()
+    f[:, [0, 2]] *= np.float32(max(1.0, side * 2.2 / 18.0))
+    mats = np.array([m for _, m in recipe("DragonGlass")], dtype=MATERIAL_DTYPE)
+    return [(np.concatenate(vs), np.concatenate(is_)), (f, fi)], mats, side
+
+
 def subdivide(vertices, indices, levels=1):
     """Midpoint subdivision (each triangle -> 4), attributes interpolated, normals renormalised.
     Used to grow the bunny towards the triangle count of the reference's missing Dragon mesh."""
