@@ -141,7 +141,7 @@ def test_bunny_recipes_one_spp_bit_exact(recipe, pipeline):
 
 @PIPELINES
 def test_c1_bunny_clearcoat_512_first_and_later_frames(pipeline):
-    # BASELINE configs[0]: BunnyClearcoat 512x512, fixed seed pixelIndex + FrameCount*719393
+    # the CPU-runnable reference case: BunnyClearcoat 512x512, fixed seed pixelIndex + FrameCount*719393
     o, g = _pair("BunnyClearcoat", 512, 512, env=(1024, 512), pipeline=pipeline)
     p = R.default_params(512, 512)
     g.set_params(p)

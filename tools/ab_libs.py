@@ -14,7 +14,7 @@ from pathtracer_amd import lib as L
 L.LIB_PATH = sys.argv[1]
 import bench
 from pathtracer_amd import renderer as R
-class A: subdivide = 0
+class A: subdivide = bench.DEFAULT_SUBDIVIDE
 work = bench.build_workload(A)
 g = R.Renderer(1920, 1080)
 g.upload_nodes(work["nodes"]); g.upload_primitives(work["prims"]); g.upload_materials(work["mats"]); g.upload_environment(work["hdri"], work["cache"])

@@ -9,7 +9,7 @@ from pathtracer_amd import renderer as R  # noqa: E402
 
 
 class A:
-    subdivide = 0
+    subdivide = bench.DEFAULT_SUBDIVIDE
 
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 16

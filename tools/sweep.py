@@ -18,7 +18,7 @@ ap.add_argument("variants", nargs="*", default=["pipeline=0", "pipeline=1"])
 ap.add_argument("--spp", type=int, default=16)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--bounces", type=int, default=8)
-ap.add_argument("--subdivide", type=int, default=0)
+ap.add_argument("--subdivide", type=int, default=bench.DEFAULT_SUBDIVIDE)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 a = ap.parse_args()
