@@ -266,7 +266,8 @@ int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, 
  * exit threshold in 64ths of the live lanes (default 32); 2: wavefront refill threshold in idle
  * lanes (default 16); 3: wavefront iterations between read-backs of the live-ray count (default 2);
  * 4: traverse grid size in blocks (0 = sized from the occupancy query); 5: megakernel hit-shading
- * threshold in 64ths of the live lanes (default 16): hits wait until that share of the wave holds one. */
+ * threshold in 64ths of the live lanes (default 16): hits wait until that share of the wave holds one;
+ * 6: longest-tile-first launch order from the previous launch's per-tile cost (default 1). */
 int pt_debug_set_tuning(pt_ctx* ctx, int key, int value);
 
 /* Profiling hook, not part of the drop-in surface (no counterpart in the reference): wave-level
@@ -277,6 +278,10 @@ int pt_debug_set_tuning(pt_ctx* ctx, int key, int value);
  * [10] lanes finishing a sample, [11] lanes starting a sample, [12] shader clock ticks waves spent in
  * shading phases, [13] in traversal phases, [14] of [12] in the hit block, [15] of [12] in the miss block. */
 int pt_debug_get_profile(pt_ctx* ctx, uint64_t out16[16]);
+/* Profiling hook (no counterpart in the reference): device wall-clock ticks at the start and end of every
+ * wave of the most recent pt_dispatch_counted() under the megakernel scheduler, as (start, end) pairs
+ * in tile order; *clock_khz_out = tick rate.  NULL pairs_out queries the count. */
+int pt_debug_get_wave_times(pt_ctx* ctx, uint64_t* pairs_out, size_t capacity, size_t* count_out, int* clock_khz_out);
 
 /* Test hook, not part of the drop-in surface (no counterpart in the reference): evaluates one
  * float32 building block of the kernels element-wise on the device so that tests can compare it

@@ -404,9 +404,10 @@ __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(
     const unsigned tid = threadIdx.x;
     int* stack = s_stack + tid;
 
-    // Consecutive blocks go to different XCDs, so taking tiles in row-major order spreads every
-    // image region -- cheap sky and expensive geometry alike -- evenly over the 8 XCDs.
-    const unsigned tile = blockIdx.x;
+    // Consecutive blocks go to different XCDs, so any block -> tile map that does not cluster
+    // expensive tiles on one XCD keeps the eight of them equally loaded: row-major order without
+    // cost information, descending cost of the previous launch with it.
+    const unsigned tile = P.tileOrder ? P.tileOrder[blockIdx.x] : blockIdx.x;
     const unsigned tileX = tile % P.tilesX, tileY = tile / P.tilesX;
     const unsigned wave = tid >> 6, lane = tid & 63u;
     const unsigned px = tileX * kMegaTile + (wave & 1u) * 8u + (lane & 7u);
@@ -427,6 +428,7 @@ __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(
     bool hasExt = false;
 
     unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // wave-uniform, counting build only
+    const unsigned long long waveStart = wall_clock64();
     for (;;) {
         // ================================================================ shading phase
         unsigned long long tick = 0;
@@ -551,6 +553,10 @@ __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(
 
     // counters: wave-level reduction, one atomic per wave and counter
     const unsigned sRays = waveSum(nRays), sShadow = waveSum(nShadow), sHits = waveSum(nHits), sSamples = waveSum(nSamples);
+    if (kMegaThreads == 64 && lane == 0) {
+        const unsigned long long lived = wall_clock64() - waveStart;
+        P.tileCost[tile] = lived > 0xffffffffull ? 0xffffffffu : (unsigned)lived;
+    }
     if (lane == 0) {
         atomicAdd(&counters->raysClosest, (unsigned long long)sRays);
         atomicAdd(&counters->raysAny, (unsigned long long)sShadow);
@@ -564,6 +570,10 @@ __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(
             atomicAdd(&counters->triangleTests, (unsigned long long)sTris);
             atomicMax(&counters->maxStack, m);
             for (int i = 0; i < 16; i++) atomicAdd(&counters->profile[i], prof[i]);
+            if (P.waveTimes) {
+                P.waveTimes[2 * (size_t)(tile * (kMegaThreads / 64) + wave)] = waveStart;
+                P.waveTimes[2 * (size_t)(tile * (kMegaThreads / 64) + wave) + 1] = wall_clock64();
+            }
         }
     }
 }

@@ -102,6 +102,12 @@ struct pt_ctx {
     DeviceBuffer dImages[3];
     DeviceBuffer dCounters;
     DeviceBuffer dRgbStaging;  // pt_read_image_rgb
+    DeviceBuffer dWaveTimes;   // counting dispatches: start / end ticks per wave
+    // longest-tile-first launch order: ticks per tile of the previous launch, sorted descending
+    DeviceBuffer dTileCost, dTileCostSorted, dTileIds, dTileOrder, dTileSortTemp;
+    size_t tileCostTiles = 0, tileSortBytes = 0;
+    bool tileCostValid = false, tileOrdering = true;
+    size_t waveTimeCount = 0;
     // geometry built on the device (pt_build_bvh_device): the tree in the reference's layouts, kept for
     // pt_download_bvh; dNodes / dTriangles / dShading are filled by the builder itself
     DeviceBuffer dRefNodes, dRefPrims;
@@ -331,7 +337,8 @@ int wavefrontDispatch(pt_ctx* c, const DevParams& P, const DevScene& S, const Im
     return PT_OK;
 }
 
-int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t frameStride, bool counted)
+int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t frameStride, bool counted, bool firstPart = true,
+                 bool lastPart = true)
 {
     if (!c) return fail(PT_ERR_INVALID, "null context");
     if (frameCount == 0) return PT_OK;
@@ -387,12 +394,49 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
     P.travExitNum = c->travExitNum;
     P.refillMin = c->refillMin;
     P.hitMinNum = c->hitMinNum;
-    HIP_TRY(hipMemsetAsync(c->dCounters.ptr, 0, sizeof(DevCounters), c->stream));
+    P.waveTimes = nullptr;
+    if (counted && c->pipeline == 0) {
+        c->waveTimeCount = (size_t)P.tilesX * P.tilesY * (kMegaThreads / 64);
+        HIP_TRY(c->dWaveTimes.ensure(c->waveTimeCount * 16));
+        HIP_TRY(hipMemsetAsync(c->dWaveTimes.ptr, 0, c->waveTimeCount * 16, c->stream));
+        P.waveTimes = (unsigned long long*)c->dWaveTimes.ptr;
+    }
+    if (firstPart) HIP_TRY(hipMemsetAsync(c->dCounters.ptr, 0, sizeof(DevCounters), c->stream));
     DevCounters* ctr = (DevCounters*)c->dCounters.ptr;
     Images img{imagePtr(c, 0), imagePtr(c, 1), imagePtr(c, 2)};
     const bool deep = c->maxDepth > 32;
-    HIP_TRY(hipEventRecord(c->evStart, c->stream));
+    if (firstPart) HIP_TRY(hipEventRecord(c->evStart, c->stream));
     if (c->pipeline == 0) {
+        // Tiles are handed to the grid's blocks longest first: the cost of a tile (ticks its wave
+        // lived in the previous launch) varies by an order of magnitude, and a launch that reaches
+        // its expensive tiles last ends in a long, nearly empty tail.
+        const size_t tiles = (size_t)P.tilesX * P.tilesY;
+        if (c->tileCostTiles != tiles) {
+            HIP_TRY(c->dTileCost.ensure(tiles * 4));
+            HIP_TRY(c->dTileCostSorted.ensure(tiles * 4));
+            HIP_TRY(c->dTileIds.ensure(tiles * 4));
+            HIP_TRY(c->dTileOrder.ensure(tiles * 4));
+            std::vector<uint32_t> ids(tiles);
+            for (size_t i = 0; i < tiles; i++) ids[i] = (uint32_t)i;
+            HIP_TRY(hipMemcpyAsync(c->dTileIds.ptr, ids.data(), tiles * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));  // `ids` dies with this scope
+            c->tileSortBytes = 0;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, c->tileSortBytes, (const uint32_t*)c->dTileCost.ptr,
+                                                                 (uint32_t*)c->dTileCostSorted.ptr, (const uint32_t*)c->dTileIds.ptr,
+                                                                 (uint32_t*)c->dTileOrder.ptr, (int)tiles, 0, 32, c->stream));
+            HIP_TRY(c->dTileSortTemp.ensure(c->tileSortBytes));
+            c->tileCostTiles = tiles;
+            c->tileCostValid = false;
+        }
+        P.tileCost = (unsigned int*)c->dTileCost.ptr;
+        P.tileOrder = nullptr;
+        if (c->tileCostValid && c->tileOrdering) {
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(c->dTileSortTemp.ptr, c->tileSortBytes, (const uint32_t*)c->dTileCost.ptr,
+                                                                 (uint32_t*)c->dTileCostSorted.ptr, (const uint32_t*)c->dTileIds.ptr,
+                                                                 (uint32_t*)c->dTileOrder.ptr, (int)tiles, 0, 32, c->stream));
+            P.tileOrder = (const unsigned int*)c->dTileOrder.ptr;
+        }
+        c->tileCostValid = true;
         const dim3 grid(P.tilesX * P.tilesY), block(kMegaThreads);
         if (counted) {
             if (deep)
@@ -410,9 +454,23 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
         int rc2 = wavefrontDispatch(c, P, S, img, ctr, counted);
         if (rc2 != PT_OK) return rc2;
     }
-    HIP_TRY(hipEventRecord(c->evStop, c->stream));
+    if (lastPart) HIP_TRY(hipEventRecord(c->evStop, c->stream));
     c->timed = true;
     return PT_OK;
+}
+
+// A launch of many frames with no tile costs on record yet (first launch, new image size, new
+// geometry) is split: a short probe launch measures the costs, the rest runs longest tile first.
+// Frame order per pixel is unchanged, so are the results.
+int dispatchSplit(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t frameStride, bool counted)
+{
+    if (c && c->pipeline == 0 && c->tileOrdering && !c->tileCostValid && frameCount >= 8) {
+        const uint32_t probe = frameCount >= 64 ? 4u : 2u;
+        int rc = dispatchImpl(c, frameFirst, probe, frameStride, counted, true, false);
+        if (rc != PT_OK) return rc;
+        return dispatchImpl(c, frameFirst + probe * frameStride, frameCount - probe, frameStride, counted, false, true);
+    }
+    return dispatchImpl(c, frameFirst, frameCount, frameStride, counted);
 }
 
 }  // namespace
@@ -464,7 +522,7 @@ void pt_destroy(pt_ctx* c)
     if (!c) return;
     DeviceGuard guard(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DeviceBuffer* all[] = {&c->dRefNodes, &c->dRefPrims, &c->dRgbStaging, &c->dNodes, &c->dTriangles, &c->dShading, &c->dMaterials, &c->dTextures, &c->dTexels,
+    DeviceBuffer* all[] = {&c->dTileCost, &c->dTileCostSorted, &c->dTileIds, &c->dTileOrder, &c->dTileSortTemp, &c->dWaveTimes, &c->dRefNodes, &c->dRefPrims, &c->dRgbStaging, &c->dNodes, &c->dTriangles, &c->dShading, &c->dMaterials, &c->dTextures, &c->dTexels,
                            &c->dSrgbLut, &c->dEnvColorPdf, &c->dEnvSample, &c->dImages[0], &c->dImages[1],
                            &c->dImages[2], &c->dCounters};
     for (DeviceBuffer* b : all) b->release();
@@ -518,6 +576,7 @@ int pt_upload_nodes(pt_ctx* c, const void* nodes48, size_t count)
     c->nodes.assign(p, p + count);
     c->geometryDirty = true;
     c->deviceGeometry = false;
+    c->tileCostValid = false;
     return PT_OK;
 }
 
@@ -827,12 +886,12 @@ int pt_clear(pt_ctx* c)
 
 int pt_dispatch(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t frameStride)
 {
-    return dispatchImpl(c, frameFirst, frameCount, frameStride, false);
+    return dispatchSplit(c, frameFirst, frameCount, frameStride, false);
 }
 
 int pt_dispatch_counted(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t frameStride)
 {
-    return dispatchImpl(c, frameFirst, frameCount, frameStride, true);
+    return dispatchSplit(c, frameFirst, frameCount, frameStride, true);
 }
 
 int pt_scale_images(pt_ctx* c, float scale)
@@ -921,7 +980,7 @@ int pt_scene_bytes(pt_ctx* c, uint64_t* nodeBytes, uint64_t* triangleBytes, uint
 // Tuning hook.  key 0: pipeline (0 megakernel, 1 wavefront); 1: megakernel traversal-phase exit
 // threshold in 64ths of the live lanes; 2: wavefront refill threshold (idle lanes); 3: wavefront
 // iterations between read-backs of the live-ray count; 4: traverse grid size in blocks (0 = auto);
-// 5: megakernel hit-shading threshold in 64ths of the live lanes.
+// 5: megakernel hit-shading threshold in 64ths of the live lanes; 6: longest-tile-first launch order on/off.
 int pt_debug_set_tuning(pt_ctx* c, int key, int value)
 {
     if (!c) return fail(PT_ERR_INVALID, "null context");
@@ -950,8 +1009,28 @@ int pt_debug_set_tuning(pt_ctx* c, int key, int value)
         if (value < 1 || value > 64) return fail(PT_ERR_INVALID, "hit threshold must be 1..64");
         c->hitMinNum = (uint32_t)value;
         return PT_OK;
+    case 6:
+        if (value != 0 && value != 1) return fail(PT_ERR_INVALID, "tile ordering must be 0 or 1");
+        c->tileOrdering = value != 0;
+        return PT_OK;
     default: return fail(PT_ERR_INVALID, "unknown tuning key");
     }
+}
+
+// Profiling hook: wall-clock ticks at the start and the end of every wave of the most recent
+// pt_dispatch_counted() with the megakernel scheduler, in tile order (pairs: start, end).
+int pt_debug_get_wave_times(pt_ctx* c, uint64_t* pairsOut, size_t capacity, size_t* countOut, int* clockKhzOut)
+{
+    if (!c || !countOut) return fail(PT_ERR_INVALID, "null argument");
+    *countOut = c->waveTimeCount;
+    DeviceGuard guard(c->device);
+    if (clockKhzOut) HIP_TRY(hipDeviceGetAttribute(clockKhzOut, hipDeviceAttributeWallClockRate, c->device));
+    if (!pairsOut) return PT_OK;
+    if (capacity < c->waveTimeCount) return fail(PT_ERR_INVALID, "capacity too small");
+    if (c->waveTimeCount == 0) return PT_OK;
+    HIP_TRY(hipMemcpyAsync(pairsOut, c->dWaveTimes.ptr, c->waveTimeCount * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PT_OK;
 }
 
 // Profiling hook: the 16 wave-occupancy counters of the most recent pt_dispatch_counted() with the
@@ -1122,6 +1201,7 @@ int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count)
     }
     HIP_TRY(hipStreamSynchronize(st));  // the scratch buffers die with this scope
     c->maxDepth = height;
+    c->tileCostValid = false;
     c->deviceGeometry = true;
     c->geometryDirty = false;
     c->nodes.clear();

@@ -125,10 +125,10 @@ class Renderer:
         fn = self._lib.pt_dispatch_counted if counted else self._lib.pt_dispatch
         check(fn(self._h, int(frame_first), int(frame_count), int(frame_stride)))
 
-    TUNING_KEYS = {"pipeline": 0, "trav_exit": 1, "refill_min": 2, "check_every": 3, "traverse_blocks": 4, "hit_min": 5}
+    TUNING_KEYS = {"pipeline": 0, "trav_exit": 1, "refill_min": 2, "check_every": 3, "traverse_blocks": 4, "hit_min": 5, "tile_order": 6}
 
     def set_tuning(self, **kw):
-        """pipeline=0|1 (megakernel|wavefront), trav_exit, refill_min, check_every, traverse_blocks, hit_min."""
+        """pipeline=0|1 (megakernel|wavefront), trav_exit, refill_min, check_every, traverse_blocks, hit_min, tile_order."""
         for k, v in kw.items():
             check(self._lib.pt_debug_set_tuning(self._h, self.TUNING_KEYS[k], int(v)))
 
@@ -136,6 +136,16 @@ class Renderer:
         out = (ctypes.c_uint64 * 16)()
         check(self._lib.pt_debug_get_profile(self._h, out))
         return list(out)
+
+    def wave_times(self):
+        """-> ((n, 2) uint64 start/end ticks per wave in tile order, tick rate in kHz) of the last counted dispatch."""
+        n, khz = ctypes.c_size_t(), ctypes.c_int()
+        check(self._lib.pt_debug_get_wave_times(self._h, None, 0, ctypes.byref(n), ctypes.byref(khz)))
+        out = np.zeros((n.value, 2), np.uint64)
+        if n.value:
+            check(self._lib.pt_debug_get_wave_times(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n.value,
+                                                    ctypes.byref(n), ctypes.byref(khz)))
+        return out, khz.value
 
     def scale_images(self, scale):
         check(self._lib.pt_scale_images(self._h, float(scale)))

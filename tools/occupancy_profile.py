@@ -4,6 +4,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
 import bench  # noqa: E402
 from pathtracer_amd import renderer as R  # noqa: E402
 
@@ -35,3 +36,15 @@ print(f"  traversal iterations per shading phase {pr[0] / pr[9]:.1f}")
 print(f"  wave clock ticks: shading phases {pr[12]} ({pr[12] / max(pr[12] + pr[13], 1):.1%}), traversal phases {pr[13]}; "
       f"per shading phase {pr[12] / pr[9]:.0f}, per traversal iteration {pr[13] / pr[0]:.0f}")
 print(f"  of the shading ticks: miss block {pr[15] / pr[12]:.1%}, hit block {pr[14] / pr[12]:.1%}, finish + new {1 - (pr[14] + pr[15]) / pr[12]:.1%}")
+wt, khz = g.wave_times()
+if len(wt):
+    t0 = wt[:, 0].min()
+    start, end = (wt[:, 0] - t0) / khz, (wt[:, 1] - t0) / khz  # ms
+    span = end.max()
+    dur = end - start
+    print(f"wave lifetimes: {len(wt)} waves, kernel span {span:.2f} ms, mean {dur.mean():.3f} ms, median {np.median(dur):.3f}, "
+          f"p90 {np.percentile(dur, 90):.3f}, max {dur.max():.3f}; sum of lifetimes / span = {dur.sum() / span:.0f} waves resident on average")
+    edges = np.linspace(0, span, 11)
+    conc = [((start < b) & (end > a)).sum() for a, b in zip(edges[:-1], edges[1:])]
+    print("  waves alive per tenth of the span:", conc)
+    print(f"  last wave to start began at {start.max():.2f} ms; waves still running at 90% of the span: {(end > 0.9 * span).sum()}")
