@@ -43,11 +43,12 @@
 namespace ptcore {
 
 constexpr int kBlockThreads = 256;
-// Waves per SIMD the megakernel is compiled for: 3 gives the register allocator 168 VGPRs (a
-// few dozen spilled values); 4 halves that budget and spills ~95, 5 spills ~185 -- both measured
-// slower than 3 on the benchmark scene.
+// Waves per SIMD the megakernel is compiled for.  Measured on the benchmark scene with every wave
+// slot kept busy (longest-tile-first launch order): 4 waves (128 VGPRs, ~110 spilled values, all
+// outside the traversal loop) 54.4 ms per 64-spp launch, 3 waves (168 VGPRs, 25 spills) 56.5 ms,
+// 2 waves 73.6 ms, 5 waves (96 VGPRs, ~185 spills) 99 ms.
 #ifndef PT_WAVES_PER_SIMD
-#define PT_WAVES_PER_SIMD 3
+#define PT_WAVES_PER_SIMD 4
 #endif
 // Threads per megakernel block: 64 (one wave, one 8x8 pixel tile) or 256 (a 16x16 tile).
 #ifndef PT_MEGA_THREADS

@@ -22,7 +22,7 @@ p = R.default_params(1920, 1080); p.max_bounces = 8; g.set_params(p)
 g.dispatch(1, 2, 1); g.synchronize()
 ms = []
 for r in range(4):
-    g.clear(); g.dispatch(1, 16, 1); g.synchronize(); ms.append(g.last_dispatch_ms())
+    g.clear(); g.dispatch(1, 64, 1); g.synchronize(); ms.append(g.last_dispatch_ms())
 st = g.stats(); rays = st.rays_closest + st.rays_any
 print("%%-50s median %%8.3f ms  min %%8.3f  -> %%8.1f Mrays/s" %% (os.path.basename(sys.argv[1]), np.median(ms), min(ms), rays / np.median(ms) / 1e3))
 ''' % ROOT
