@@ -108,14 +108,16 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bounces", type=int, default=8)
-    ap.add_argument("--subdivide", type=int, default=DEFAULT_SUBDIVIDE,
-                    help="midpoint-subdivide the bunny this many times (default 1: 576 k triangles)")
+    ap.add_argument("--subdivide", type=int, default=None,
+                    help="midpoint-subdivide the bunny this many times (default 1: 576 k triangles; 0 with --copies)")
     ap.add_argument("--copies", type=int, default=1,
                     help="instanced-scene stress: this many bunnies flattened on a jittered grid (139 = 20 M triangles)")
     ap.add_argument("--bvh", choices=["host", "device"], default="host",
                     help="host: the reference's sweep-SAH builder (bit-identical tree); device: GPU linear BVH")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.subdivide is None:
+        args.subdivide = DEFAULT_SUBDIVIDE if args.copies == 1 else 0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
