@@ -404,7 +404,6 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
     if (firstPart) HIP_TRY(hipMemsetAsync(c->dCounters.ptr, 0, sizeof(DevCounters), c->stream));
     DevCounters* ctr = (DevCounters*)c->dCounters.ptr;
     Images img{imagePtr(c, 0), imagePtr(c, 1), imagePtr(c, 2)};
-    const bool deep = c->maxDepth > 32;
     if (firstPart) HIP_TRY(hipEventRecord(c->evStart, c->stream));
     if (c->pipeline == 0) {
         // Tiles are handed to the grid's blocks longest first: the cost of a tile (ticks its wave
@@ -438,14 +437,20 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
         }
         c->tileCostValid = true;
         const dim3 grid(P.tilesX * P.tilesY), block(kMegaThreads);
+        // the LDS stack is sized in three steps: 8, 12 or 16 KB per wave
+        const int stackClass = c->maxDepth <= 32 ? 0 : (c->maxDepth <= 48 ? 1 : 2);
         if (counted) {
-            if (deep)
+            if (stackClass == 2)
                 hipLaunchKernelGGL((renderKernel<64, true>), grid, block, 0, c->stream, P, S, img, ctr);
+            else if (stackClass == 1)
+                hipLaunchKernelGGL((renderKernel<48, true>), grid, block, 0, c->stream, P, S, img, ctr);
             else
                 hipLaunchKernelGGL((renderKernel<32, true>), grid, block, 0, c->stream, P, S, img, ctr);
         } else {
-            if (deep)
+            if (stackClass == 2)
                 hipLaunchKernelGGL((renderKernel<64, false>), grid, block, 0, c->stream, P, S, img, ctr);
+            else if (stackClass == 1)
+                hipLaunchKernelGGL((renderKernel<48, false>), grid, block, 0, c->stream, P, S, img, ctr);
             else
                 hipLaunchKernelGGL((renderKernel<32, false>), grid, block, 0, c->stream, P, S, img, ctr);
         }
