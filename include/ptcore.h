@@ -192,6 +192,16 @@ int pt_process_buffers_device(pt_ctx* ctx);
 int pt_download_bvh(pt_ctx* ctx, void* nodes48_out, size_t node_capacity, size_t* node_count_out, void* prims112_out,
                     size_t prim_capacity, size_t* prim_count_out);
 
+/* On-disk cache of a built BVH (no counterpart in the reference, which rebuilds the tree at every
+ * start: PathTracingRenderer.cpp:566-613).  The key is a hash of the UNSORTED primitive soup the tree
+ * was built from, so a file built from other geometry is refused (PT_ERR_STATE), as is a missing,
+ * truncated or corrupt one.  pt_bvh_cache_load with NULL outputs returns the counts of a valid file. */
+int pt_bvh_cache_key(const void* primitives, size_t bytes, uint64_t* key_out);
+int pt_bvh_cache_save(const char* path, uint64_t key, const void* nodes48, size_t node_count, const void* prims112,
+                      size_t prim_count);
+int pt_bvh_cache_load(const char* path, uint64_t key, void* nodes48_out, size_t node_capacity, size_t* node_count_out,
+                      void* prims112_out, size_t prim_capacity, size_t* prim_count_out);
+
 /* glTF 2.0 / GLB scene reader: what ModelLoader::Load (ModelLoader.cpp:83-121) hands to
  * PathTracingRenderer::AddPathTracingModel, without assimp.  One sub-mesh per mesh primitive, in file
  * order; node transforms are ignored as in the reference; vertices are {pos, nor, uv} with V flipped

@@ -39,6 +39,13 @@ std::string PackScene(const RefNodeAlign* nodes, size_t nodeCount, const RefPrim
 std::string PackMaterials(const RefMaterialAlign* mats, size_t count, size_t textureSlots,
                           const std::vector<int>& slotToTexture, std::vector<DevMaterial>& out);
 
+// host_cache.cpp: on-disk cache of a built BVH, keyed by a hash of the unsorted primitive soup.
+uint64_t Fnv1a64(const void* data, size_t bytes, uint64_t h = 1469598103934665603ull);
+std::string SaveBvhCache(const std::string& path, uint64_t key, const RefNodeAlign* nodes, size_t nodeCount,
+                         const RefPrimitiveAlign* prims, size_t primCount);
+std::string LoadBvhCache(const std::string& path, uint64_t key, std::vector<RefNodeAlign>& nodes,
+                         std::vector<RefPrimitiveAlign>& prims);
+
 // host_gltf.cpp: glTF 2.0 / GLB reader (ModelLoader::Load + GenerateMaterial without assimp).
 struct GltfMaterial {  // Material::MaterialAttributes (Material.h:43-59), same order and defaults
     float emission[3] = {0.0f, 0.0f, 0.0f};

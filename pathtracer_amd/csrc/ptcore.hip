@@ -766,6 +766,43 @@ int pt_calculate_hdri_cache(const float* hdri, int width, int height, float* cac
     return PT_OK;
 }
 
+int pt_bvh_cache_key(const void* primitives, size_t bytes, uint64_t* keyOut)
+{
+    if (!primitives || !keyOut) return fail(PT_ERR_INVALID, "null argument");
+    *keyOut = Fnv1a64(primitives, bytes);
+    return PT_OK;
+}
+
+int pt_bvh_cache_save(const char* path, uint64_t key, const void* nodes48, size_t nodeCount, const void* prims112, size_t primCount)
+{
+    if (!path || !nodes48 || !prims112) return fail(PT_ERR_INVALID, "null argument");
+    const std::string err = SaveBvhCache(path, key, (const RefNodeAlign*)nodes48, nodeCount, (const RefPrimitiveAlign*)prims112, primCount);
+    return err.empty() ? PT_OK : fail(PT_ERR_STATE, err);
+}
+
+int pt_bvh_cache_load(const char* path, uint64_t key, void* nodes48Out, size_t nodeCapacity, size_t* nodeCountOut,
+                      void* prims112Out, size_t primCapacity, size_t* primCountOut)
+{
+    if (!path || !nodeCountOut || !primCountOut) return fail(PT_ERR_INVALID, "null argument");
+    std::vector<RefNodeAlign> nodes;
+    std::vector<RefPrimitiveAlign> prims;
+    std::string err;
+    try {
+        err = LoadBvhCache(path, key, nodes, prims);
+    } catch (const std::bad_alloc&) {
+        return fail(PT_ERR_NOMEM, "out of host memory while reading the BVH cache");
+    }
+    if (!err.empty()) return fail(PT_ERR_STATE, err);
+    *nodeCountOut = nodes.size();
+    *primCountOut = prims.size();
+    if (!nodes48Out && !prims112Out) return PT_OK;
+    if (!nodes48Out || !prims112Out) return fail(PT_ERR_INVALID, "null output buffer");
+    if (nodeCapacity < nodes.size() || primCapacity < prims.size()) return fail(PT_ERR_INVALID, "output capacity too small");
+    std::memcpy(nodes48Out, nodes.data(), nodes.size() * sizeof(RefNodeAlign));
+    std::memcpy(prims112Out, prims.data(), prims.size() * sizeof(RefPrimitiveAlign));
+    return PT_OK;
+}
+
 struct pt_gltf {
     GltfScene scene;
 };

@@ -89,6 +89,12 @@ SYMBOLS = {
     "pt_process_buffers_device": (ctypes.c_int, [ctypes.c_void_p]),
     "pt_download_bvh": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),
                                        ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
+    "pt_bvh_cache_key": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]),
+    "pt_bvh_cache_save": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_size_t,
+                                         ctypes.c_void_p, ctypes.c_size_t]),
+    "pt_bvh_cache_load": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_size_t,
+                                         ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p, ctypes.c_size_t,
+                                         ctypes.POINTER(ctypes.c_size_t)]),
     "pt_gltf_load": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]),
     "pt_gltf_free": (None, [ctypes.c_void_p]),
     "pt_gltf_submesh_count": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]),

@@ -238,6 +238,33 @@ def align_primitives(prims100):
     return out
 
 
+def bvh_cache_key(primitives):
+    """Key of the on-disk BVH cache: hash of the unsorted primitive soup the tree is built from."""
+    a = np.ascontiguousarray(primitives)
+    key = ctypes.c_uint64()
+    check(_l.load().pt_bvh_cache_key(_ptr(a), a.nbytes, ctypes.byref(key)))
+    return key.value
+
+
+def bvh_cache_save(path, key, nodes48, prims112):
+    n, p = np.ascontiguousarray(nodes48), np.ascontiguousarray(prims112)
+    assert n.nbytes % 48 == 0 and p.nbytes % 112 == 0
+    check(_l.load().pt_bvh_cache_save(str(path).encode(), key, _ptr(n), n.nbytes // 48, _ptr(p), p.nbytes // 112))
+
+
+def bvh_cache_load(path, key):
+    """-> (nodes48 (n, 12) float32 view, prims112 (m, 28) float32 view); PtError if the file is missing,
+    stale (other key), truncated or corrupt."""
+    lib = _l.load()
+    nn, npr = ctypes.c_size_t(), ctypes.c_size_t()
+    check(lib.pt_bvh_cache_load(str(path).encode(), key, None, 0, ctypes.byref(nn), None, 0, ctypes.byref(npr)))
+    nodes = np.zeros((nn.value, 12), np.float32)
+    prims = np.zeros((npr.value, 28), np.float32)
+    check(lib.pt_bvh_cache_load(str(path).encode(), key, _ptr(nodes), nn.value, ctypes.byref(nn), _ptr(prims), npr.value,
+                                ctypes.byref(npr)))
+    return nodes, prims
+
+
 def calculate_hdri_cache(hdri_rgb):
     a = np.ascontiguousarray(hdri_rgb, dtype=np.float32)
     h, w = a.shape[:2]

@@ -206,3 +206,35 @@ def test_oracle_math_close_to_libm():
     assert np.max(np.abs(got - want) / np.maximum(want, 1e-30)) < 1e-5
     assert ob.eval_math(4, np.array([0.0], np.float32), np.array([0.5], np.float32))[0] == 0.0
     assert ob.eval_math(4, np.array([0.25], np.float32), np.array([0.5], np.float32))[0] == np.float32(0.5)
+
+
+def test_bvh_cache_round_trip_and_rejections(tmp_path):
+    from pathtracer_amd.lib import PtError
+    from tests.common import soup
+    from pathtracer_amd import scenes
+    prims100, _ = soup(scenes.recipe("TorusMixed"))
+    key = R.bvh_cache_key(prims100)
+    assert key == R.bvh_cache_key(prims100.copy()) and key != R.bvh_cache_key(prims100[::-1].copy())
+    sorted100, nodes40 = R.build_bvh_sah(prims100, 4)
+    nodes48, prims112 = R.align_nodes(nodes40), R.align_primitives(sorted100)
+    path = tmp_path / "torus.ptbvh"
+    R.bvh_cache_save(path, key, nodes48, prims112)
+    n2, p2 = R.bvh_cache_load(path, key)
+    assert np.array_equal(n2.view(np.uint32), np.ascontiguousarray(nodes48).view(np.uint32).reshape(n2.shape))
+    assert np.array_equal(p2.view(np.uint32), np.ascontiguousarray(prims112).view(np.uint32).reshape(p2.shape))
+    with pytest.raises(PtError, match="stale"):
+        R.bvh_cache_load(path, key ^ 1)
+    with pytest.raises(PtError, match="no cache file"):
+        R.bvh_cache_load(tmp_path / "absent.ptbvh", key)
+    blob = path.read_bytes()
+    (tmp_path / "cut.ptbvh").write_bytes(blob[:-100])
+    with pytest.raises(PtError, match="truncated"):
+        R.bvh_cache_load(tmp_path / "cut.ptbvh", key)
+    flipped = bytearray(blob)
+    flipped[len(blob) // 2] ^= 0x40
+    (tmp_path / "flip.ptbvh").write_bytes(bytes(flipped))
+    with pytest.raises(PtError, match="corrupt"):
+        R.bvh_cache_load(tmp_path / "flip.ptbvh", key)
+    (tmp_path / "junk.ptbvh").write_bytes(b"not a cache")
+    with pytest.raises(PtError, match="not a BVH cache"):
+        R.bvh_cache_load(tmp_path / "junk.ptbvh", key)
