@@ -46,6 +46,9 @@ class ShardedRenderer:
         self.renderer.bind_images(*(self.images[k].data_ptr() for k in range(3)))
         self.renderer.set_stream(self.stream.cuda_stream)
         self.samples_local = 0
+        # The collective runs on its own stream so that the next step's kernel does not wait for it.
+        self.comm_stream = torch.cuda.Stream(self.device) if self.world > 1 else None
+        self._reduced = None  # event: the last all-reduce into `total` has finished
 
     def set_params(self, params):
         params.accumulate_mode = 1 if self.world > 1 else params.accumulate_mode
@@ -69,16 +72,27 @@ class ShardedRenderer:
 
     def reduce(self):
         """Sum the accumulation buffers over ranks into `self.total` (one RCCL all-reduce of the
-        three images); this rank's own sums stay intact so rendering can continue.  A no-op on one
-        GPU, where `total` aliases `images`."""
+        three images); this rank's own sums stay intact so rendering can continue: the snapshot is
+        taken on the render stream, the collective runs on a second stream and overlaps the next
+        step's kernel.  A no-op on one GPU, where `total` aliases `images`."""
         if self.world > 1:
             with torch.cuda.stream(self.stream):
+                if self._reduced is not None:
+                    self.stream.wait_event(self._reduced)  # the previous collective still reads `total`
                 self.total.copy_(self.images)
+                copied = torch.cuda.Event()
+                copied.record(self.stream)
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(copied)
                 reduce_sum(self.total)
+                self._reduced = torch.cuda.Event()
+                self._reduced.record(self.comm_stream)
 
     def resolve(self, total_samples):
         """Mean images after reduce(): the summed buffers divided by the global sample count."""
         with torch.cuda.stream(self.stream):
+            if self._reduced is not None:
+                self.stream.wait_event(self._reduced)
             out = self.total / float(total_samples) if self._sum_mode else self.total.clone()
         self.stream.synchronize()
         return out

@@ -21,19 +21,19 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cu
 nodes, prims, mats = built_scene("TorusMixed")
 hdri, cache = environment(256, 128)
 w, h, spp = 256, 192, 8
-sr = ShardedRenderer(w, h, 0, 0, 1)
-sr.world = 2  # take the N > 1 branches (sum mode, separate total buffer) ...
-sr.total = torch.zeros_like(sr.images)
+from pathtracer_amd import distributed as D  # noqa: E402
+D.reduce_sum = lambda t, group=None: dist.all_reduce(t, op=dist.ReduceOp.SUM)  # even with one rank
+sr = ShardedRenderer(w, h, 0, 0, 2)  # world 2: sum mode, separate total buffer, collective stream
 g = sr.renderer
 g.upload_nodes(nodes); g.upload_primitives(prims); g.upload_materials(mats); g.upload_environment(hdri, cache)
 p = R.default_params(w, h)
 sr.set_params(p)
-sr.world = 1  # ... but deal all frames to this rank
 sr.clear()
-sr.render_step(0, spp)
-with torch.cuda.stream(sr.stream):
-    sr.total.copy_(sr.images)
-    dist.all_reduce(sr.total, op=dist.ReduceOp.SUM)
+half = spp // 2
+g.dispatch(1, half, 1)          # two steps with a reduce after each, like the benchmark loop
+sr.reduce()
+g.dispatch(1 + half, spp - half, 1)
+sr.reduce()
 out = sr.resolve(spp).cpu().numpy()
 # reference: the plain single-GPU running mean of the same frames
 ref = R.Renderer(w, h)
