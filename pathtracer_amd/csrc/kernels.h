@@ -398,30 +398,47 @@ PT_DEV unsigned waveMax(unsigned v)
 // ================================================================================ megakernel
 enum LaneMode : int { kModeNew = 0, kModeShade = 1, kModeTrav = 2, kModeFinish = 3, kModeDone = 4 };
 
+// Number of set bits of `mask` below the calling lane.
+PT_DEV unsigned laneRank(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
 template <int STACK, bool COUNT>
 __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(DevParams P, DevScene S, Images img, DevCounters* counters)
 {
+    static_assert(kMegaThreads == 64, "one wave per block: the sample pool below is wave-wide");
     __shared__ int s_stack[STACK * kMegaThreads];
-    const unsigned tid = threadIdx.x;
-    int* stack = s_stack + tid;
+    __shared__ unsigned s_pixel[64];  // the tile's pixels that lie inside the image, compacted
+    const unsigned lane = threadIdx.x, wave = 0;
+    int* stack = s_stack + lane;
 
     // Consecutive blocks go to different XCDs, so any block -> tile map that does not cluster
     // expensive tiles on one XCD keeps the eight of them equally loaded: row-major order without
     // cost information, descending cost of the previous launch with it.
     const unsigned tile = P.tileOrder ? P.tileOrder[blockIdx.x] : blockIdx.x;
     const unsigned tileX = tile % P.tilesX, tileY = tile / P.tilesX;
-    const unsigned wave = tid >> 6, lane = tid & 63u;
-    const unsigned px = tileX * kMegaTile + (wave & 1u) * 8u + (lane & 7u);
-    const unsigned py = tileY * kMegaTile + (wave >> 1) * 8u + (lane >> 3);
-    const bool inside = px < P.width && py < P.height;
-    const size_t texel = (size_t)py * P.width + px;
+
+    // The wave owns the tile's (pixel, sample) pairs as one pool, handed out in sample-major order:
+    // a lane that finishes a path takes the next pair, whichever pixel it belongs to, so no lane
+    // idles while the tile has work, and an expensive pixel's samples are traced by many lanes at
+    // once.  Finished samples are not accumulated here (the running mean of a pixel must take its
+    // samples in FrameCount order): they go to the sample buffer, one record per (sample, pixel),
+    // and resolveKernel folds them into the images in order afterwards.
+    const bool inside = tileX * kMegaTile + (lane & 7u) < P.width && tileY * kMegaTile + (lane >> 3) < P.height;
+    const unsigned long long insideMask = __ballot(inside);
+    const unsigned nInside = (unsigned)__popcll(insideMask);
+    if (inside) s_pixel[laneRank(insideMask)] = lane;
+    __syncthreads();
+    const unsigned poolSize = nInside * P.frameCount;
+    unsigned poolNext = 0;  // wave-uniform
 
     unsigned nRays = 0, nShadow = 0, nHits = 0, nSamples = 0;
     StepCounters sc{0u, 0u, 0u};
 
     PathState ps{};
     ps.k = 0;
-    const unsigned kEnd = inside ? P.frameCount : 0u;
+    unsigned pixel = 0;  // which pixel of the tile (0..63, row-major) the lane's current sample belongs to
     int mode = kModeNew;
     Query q{};
     v3 extDir = splat(0.0f);   // direction of the extension ray waiting behind a shadow ray
@@ -483,26 +500,40 @@ __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(
             prof[12] += now - tick;
             tick = now;
         }
+        // a finished sample goes to its record of the sample buffer
         if (COUNT) prof[10] += (unsigned)__popcll(__ballot(mode == kModeFinish));
         if (mode == kModeFinish) {
-            accumulateSample(P, img, texel, ps);
-            ps.k++;
+            const unsigned px = tileX * kMegaTile + (pixel & 7u), py = tileY * kMegaTile + (pixel >> 3);
+            float4* rec = reinterpret_cast<float4*>(P.samples) + ((size_t)ps.k * P.pixels + ((size_t)py * P.width + px)) * 3u;
+            rec[0] = make_float4(ps.radiance.x, ps.radiance.y, ps.radiance.z, 0.0f);
+            rec[1] = make_float4(ps.albedoRes.x, ps.albedoRes.y, ps.albedoRes.z, 0.0f);
+            rec[2] = make_float4(ps.normalRes.x, ps.normalRes.y, ps.normalRes.z, 0.0f);
             mode = kModeNew;
         }
-        if (COUNT) prof[11] += (unsigned)__popcll(__ballot(mode == kModeNew && ps.k < kEnd));
-        if (mode == kModeNew) {
-            if (ps.k < kEnd) {
-                v3 ro, rd;
-                startSample(P, px, py, ps, ro, rd);
-                hasExt = false;
-                nSamples++;
-                nRays++;
-                beginQuery(q, P.rootRef, ro, rd, false);
-                mode = kModeTrav;
-            } else {
-                mode = kModeDone;
+        // lanes without a sample take the next (pixel, sample) pairs of the pool
+        const unsigned long long wantMask = __ballot(mode == kModeNew);
+        if (wantMask != 0ull) {
+            const unsigned item = poolNext + laneRank(wantMask);
+            if (mode == kModeNew) {
+                if (item < poolSize) {
+                    const unsigned slot = nInside == 64u ? (item & 63u) : item % nInside;
+                    ps.k = nInside == 64u ? (item >> 6) : item / nInside;
+                    pixel = s_pixel[slot];
+                    v3 ro, rd;
+                    startSample(P, tileX * kMegaTile + (pixel & 7u), tileY * kMegaTile + (pixel >> 3), ps, ro, rd);
+                    hasExt = false;
+                    nSamples++;
+                    nRays++;
+                    beginQuery(q, P.rootRef, ro, rd, false);
+                    mode = kModeTrav;
+                } else {
+                    mode = kModeDone;
+                }
             }
+            const unsigned want = (unsigned)__popcll(wantMask);
+            poolNext = poolSize - poolNext < want ? poolSize : poolNext + want;
         }
+        if (COUNT) prof[11] += (unsigned)__popcll(wantMask & __ballot(mode == kModeTrav));
         if (__ballot(mode == kModeTrav || mode == kModeShade) == 0ull) break;
         // Leave the traversal phase once fewer than `threshold` lanes are traversing; lanes that
         // are done for good or wait for the hit block do not count against the wave.
@@ -577,6 +608,27 @@ __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(
             }
         }
     }
+}
+
+// Folds the sample buffer into the images: one thread per pixel applies its samples in FrameCount
+// order with the shader's accumulation expression (pathtracing.comp:248-260), i.e. the same
+// rounding sequence as frame-by-frame dispatches.  Streams frameCount x 48 B per pixel, coalesced.
+__global__ void resolveKernel(DevParams P, Images img)
+{
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P.pixels) return;
+    float4 r = img.radiance[p], a = img.albedo[p], n = img.normal[p];
+    for (unsigned k = 0; k < P.frameCount; k++) {
+        const float4* rec = reinterpret_cast<const float4*>(P.samples) + ((size_t)k * P.pixels + p) * 3u;
+        const float4 xr = rec[0], xa = rec[1], xn = rec[2];
+        const float weight = 1.0f / (float)(P.frameFirst + k * P.frameStride);
+        r = accumulate(r, mk3(xr.x, xr.y, xr.z), weight, P.accumulateMode);
+        a = accumulate(a, mk3(xa.x, xa.y, xa.z), weight, P.accumulateMode);
+        n = accumulate(n, mk3(xn.x, xn.y, xn.z), weight, P.accumulateMode);
+    }
+    img.radiance[p] = r;
+    img.albedo[p] = a;
+    img.normal[p] = n;
 }
 
 // ================================================================================= wavefront

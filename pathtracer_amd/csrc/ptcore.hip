@@ -107,6 +107,9 @@ struct pt_ctx {
     DeviceBuffer dTileCost, dTileCostSorted, dTileIds, dTileOrder, dTileSortTemp;
     size_t tileCostTiles = 0, tileSortBytes = 0;
     bool tileCostValid = false, tileOrdering = true;
+    // finished samples of one launch, 48 B per (sample, pixel); resolved into the images after the launch
+    DeviceBuffer dSamples;
+    uint64_t sampleBudgetBytes = 8ull << 30;
     size_t waveTimeCount = 0;
     // geometry built on the device (pt_build_bvh_device): the tree in the reference's layouts, kept for
     // pt_download_bvh; dNodes / dTriangles / dShading are filled by the builder itself
@@ -427,6 +430,9 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
             c->tileCostTiles = tiles;
             c->tileCostValid = false;
         }
+        HIP_TRY(c->dSamples.ensure((size_t)frameCount * (size_t)c->width * c->height * 48u));
+        P.samples = (float*)c->dSamples.ptr;
+        P.pixels = (unsigned long long)c->width * c->height;
         P.tileCost = (unsigned int*)c->dTileCost.ptr;
         P.tileOrder = nullptr;
         if (c->tileCostValid && c->tileOrdering) {
@@ -454,6 +460,7 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
             else
                 hipLaunchKernelGGL((renderKernel<32, false>), grid, block, 0, c->stream, P, S, img, ctr);
         }
+        hipLaunchKernelGGL(resolveKernel, dim3((unsigned)((P.pixels + 255) / 256)), dim3(256), 0, c->stream, P, img);
         HIP_TRY(hipGetLastError());
     } else {
         int rc2 = wavefrontDispatch(c, P, S, img, ctr, counted);
@@ -469,13 +476,21 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
 // Frame order per pixel is unchanged, so are the results.
 int dispatchSplit(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t frameStride, bool counted)
 {
-    if (c && c->pipeline == 0 && c->tileOrdering && !c->tileCostValid && frameCount >= 8) {
-        const uint32_t probe = frameCount >= 64 ? 4u : 2u;
-        int rc = dispatchImpl(c, frameFirst, probe, frameStride, counted, true, false);
+    if (!c) return fail(PT_ERR_INVALID, "null context");
+    if (c->pipeline != 0 || frameCount == 0) return dispatchImpl(c, frameFirst, frameCount, frameStride, counted);
+    // The megakernel writes one 48-byte record per (sample, pixel) and a resolve pass folds them into
+    // the images; a launch takes as many frames as the sample buffer's budget holds.
+    const uint64_t perFrame = (uint64_t)c->width * c->height * 48u;
+    uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(frameCount, c->sampleBudgetBytes / perFrame));
+    uint32_t done = 0;
+    while (done < frameCount) {
+        uint32_t n = std::min(chunk, frameCount - done);
+        if (c->tileOrdering && !c->tileCostValid && n >= 8) n = n >= 64 ? 4u : 2u;  // probe: measure tile costs first
+        int rc = dispatchImpl(c, frameFirst + done * frameStride, n, frameStride, counted, done == 0, done + n == frameCount);
         if (rc != PT_OK) return rc;
-        return dispatchImpl(c, frameFirst + probe * frameStride, frameCount - probe, frameStride, counted, false, true);
+        done += n;
     }
-    return dispatchImpl(c, frameFirst, frameCount, frameStride, counted);
+    return PT_OK;
 }
 
 }  // namespace
@@ -527,7 +542,7 @@ void pt_destroy(pt_ctx* c)
     if (!c) return;
     DeviceGuard guard(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DeviceBuffer* all[] = {&c->dTileCost, &c->dTileCostSorted, &c->dTileIds, &c->dTileOrder, &c->dTileSortTemp, &c->dWaveTimes, &c->dRefNodes, &c->dRefPrims, &c->dRgbStaging, &c->dNodes, &c->dTriangles, &c->dShading, &c->dMaterials, &c->dTextures, &c->dTexels,
+    DeviceBuffer* all[] = {&c->dSamples, &c->dTileCost, &c->dTileCostSorted, &c->dTileIds, &c->dTileOrder, &c->dTileSortTemp, &c->dWaveTimes, &c->dRefNodes, &c->dRefPrims, &c->dRgbStaging, &c->dNodes, &c->dTriangles, &c->dShading, &c->dMaterials, &c->dTextures, &c->dTexels,
                            &c->dSrgbLut, &c->dEnvColorPdf, &c->dEnvSample, &c->dImages[0], &c->dImages[1],
                            &c->dImages[2], &c->dCounters};
     for (DeviceBuffer* b : all) b->release();
