@@ -277,7 +277,8 @@ int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, 
  * lanes (default 16); 3: wavefront iterations between read-backs of the live-ray count (default 2);
  * 4: traverse grid size in blocks (0 = sized from the occupancy query); 5: megakernel hit-shading
  * threshold in 64ths of the live lanes (default 16): hits wait until that share of the wave holds one;
- * 6: longest-tile-first launch order from the previous launch's per-tile cost (default 1). */
+ * 6: longest-tile-first launch order from the previous launch's per-tile cost (default 1); 7: samples
+ * of a tile that one megakernel block traces (default 65536: the whole launch; smaller values were slower). */
 int pt_debug_set_tuning(pt_ctx* ctx, int key, int value);
 
 /* Profiling hook, not part of the drop-in surface (no counterpart in the reference): wave-level

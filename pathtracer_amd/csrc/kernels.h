@@ -410,16 +410,22 @@ __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(
     static_assert(kMegaThreads == 64, "one wave per block: the sample pool below is wave-wide");
     __shared__ int s_stack[STACK * kMegaThreads];
     __shared__ unsigned s_pixel[64];  // the tile's pixels that lie inside the image, compacted
-    const unsigned lane = threadIdx.x, wave = 0;
+    const unsigned lane = threadIdx.x;
     int* stack = s_stack + lane;
 
     // Consecutive blocks go to different XCDs, so any block -> tile map that does not cluster
     // expensive tiles on one XCD keeps the eight of them equally loaded: row-major order without
     // cost information, descending cost of the previous launch with it.
-    const unsigned tile = P.tileOrder ? P.tileOrder[blockIdx.x] : blockIdx.x;
+    // A tile's samples are split into `parts` ranges of P.samplesPerBlock, one block each, so that no
+    // single wave carries a whole expensive tile.
+    const unsigned parts = (P.frameCount + P.samplesPerBlock - 1u) / P.samplesPerBlock;
+    const unsigned tileRank = blockIdx.x / parts, part = blockIdx.x - tileRank * parts;
+    const unsigned tile = P.tileOrder ? P.tileOrder[tileRank] : tileRank;
     const unsigned tileX = tile % P.tilesX, tileY = tile / P.tilesX;
+    const unsigned kBegin = part * P.samplesPerBlock;
+    const unsigned kCount = P.frameCount - kBegin < P.samplesPerBlock ? P.frameCount - kBegin : P.samplesPerBlock;
 
-    // The wave owns the tile's (pixel, sample) pairs as one pool, handed out in sample-major order:
+    // The wave owns its (pixel, sample) pairs as one pool, handed out in sample-major order:
     // a lane that finishes a path takes the next pair, whichever pixel it belongs to, so no lane
     // idles while the tile has work, and an expensive pixel's samples are traced by many lanes at
     // once.  Finished samples are not accumulated here (the running mean of a pixel must take its
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(
     const unsigned nInside = (unsigned)__popcll(insideMask);
     if (inside) s_pixel[laneRank(insideMask)] = lane;
     __syncthreads();
-    const unsigned poolSize = nInside * P.frameCount;
+    const unsigned poolSize = nInside * kCount;
     unsigned poolNext = 0;  // wave-uniform
 
     unsigned nRays = 0, nShadow = 0, nHits = 0, nSamples = 0;
@@ -517,7 +523,7 @@ __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(
             if (mode == kModeNew) {
                 if (item < poolSize) {
                     const unsigned slot = nInside == 64u ? (item & 63u) : item % nInside;
-                    ps.k = nInside == 64u ? (item >> 6) : item / nInside;
+                    ps.k = kBegin + (nInside == 64u ? (item >> 6) : item / nInside);
                     pixel = s_pixel[slot];
                     v3 ro, rd;
                     startSample(P, tileX * kMegaTile + (pixel & 7u), tileY * kMegaTile + (pixel >> 3), ps, ro, rd);
@@ -587,7 +593,7 @@ __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(
     const unsigned sRays = waveSum(nRays), sShadow = waveSum(nShadow), sHits = waveSum(nHits), sSamples = waveSum(nSamples);
     if (kMegaThreads == 64 && lane == 0) {
         const unsigned long long lived = wall_clock64() - waveStart;
-        P.tileCost[tile] = lived > 0xffffffffull ? 0xffffffffu : (unsigned)lived;
+        atomicAdd(&P.tileCost[tile], lived > 0x0fffffffull ? 0x0fffffffu : (unsigned)lived);  // summed over the tile's blocks
     }
     if (lane == 0) {
         atomicAdd(&counters->raysClosest, (unsigned long long)sRays);
@@ -603,8 +609,8 @@ __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(
             atomicMax(&counters->maxStack, m);
             for (int i = 0; i < 16; i++) atomicAdd(&counters->profile[i], prof[i]);
             if (P.waveTimes) {
-                P.waveTimes[2 * (size_t)(tile * (kMegaThreads / 64) + wave)] = waveStart;
-                P.waveTimes[2 * (size_t)(tile * (kMegaThreads / 64) + wave) + 1] = wall_clock64();
+                P.waveTimes[2 * (size_t)blockIdx.x] = waveStart;
+                P.waveTimes[2 * (size_t)blockIdx.x + 1] = wall_clock64();
             }
         }
     }

@@ -162,6 +162,7 @@ struct DevParams {
     unsigned int* tileCost;         // megakernel: per tile, ticks its wave lived (input of the next launch's order)
     float* samples;                 // megakernel: finished samples, 3 x float4 per (sample, pixel), sample-major
     unsigned long long pixels;      // width * height
+    uint32_t samplesPerBlock;       // megakernel: samples of a tile that one block (wave) traces
     unsigned long long* waveTimes;  // counting build: per tile, wall-clock ticks at wave start and end (or null)
     uint32_t refillMin;    // wavefront: a wave refills from the ray queue once this many lanes are idle
     uint32_t hitMinNum;    // megakernel: shade hits once this many 64ths of the live lanes hold one

@@ -110,6 +110,7 @@ struct pt_ctx {
     // finished samples of one launch, 48 B per (sample, pixel); resolved into the images after the launch
     DeviceBuffer dSamples;
     uint64_t sampleBudgetBytes = 8ull << 30;
+    uint32_t samplesPerBlock = 65536;
     size_t waveTimeCount = 0;
     // geometry built on the device (pt_build_bvh_device): the tree in the reference's layouts, kept for
     // pt_download_bvh; dNodes / dTriangles / dShading are filled by the builder itself
@@ -399,7 +400,7 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
     P.hitMinNum = c->hitMinNum;
     P.waveTimes = nullptr;
     if (counted && c->pipeline == 0) {
-        c->waveTimeCount = (size_t)P.tilesX * P.tilesY * (kMegaThreads / 64);
+        c->waveTimeCount = (size_t)P.tilesX * P.tilesY * ((frameCount + c->samplesPerBlock - 1) / c->samplesPerBlock);
         HIP_TRY(c->dWaveTimes.ensure(c->waveTimeCount * 16));
         HIP_TRY(hipMemsetAsync(c->dWaveTimes.ptr, 0, c->waveTimeCount * 16, c->stream));
         P.waveTimes = (unsigned long long*)c->dWaveTimes.ptr;
@@ -433,6 +434,8 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
         HIP_TRY(c->dSamples.ensure((size_t)frameCount * (size_t)c->width * c->height * 48u));
         P.samples = (float*)c->dSamples.ptr;
         P.pixels = (unsigned long long)c->width * c->height;
+        P.samplesPerBlock = c->samplesPerBlock;
+        const unsigned parts = (frameCount + c->samplesPerBlock - 1) / c->samplesPerBlock;
         P.tileCost = (unsigned int*)c->dTileCost.ptr;
         P.tileOrder = nullptr;
         if (c->tileCostValid && c->tileOrdering) {
@@ -441,8 +444,9 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
                                                                  (uint32_t*)c->dTileOrder.ptr, (int)tiles, 0, 32, c->stream));
             P.tileOrder = (const unsigned int*)c->dTileOrder.ptr;
         }
+        HIP_TRY(hipMemsetAsync(c->dTileCost.ptr, 0, tiles * 4, c->stream));  // blocks add their lifetimes
         c->tileCostValid = true;
-        const dim3 grid(P.tilesX * P.tilesY), block(kMegaThreads);
+        const dim3 grid((unsigned)(tiles * parts)), block(kMegaThreads);
         // the LDS stack is sized in three steps: 8, 12 or 16 KB per wave
         const int stackClass = c->maxDepth <= 32 ? 0 : (c->maxDepth <= 48 ? 1 : 2);
         if (counted) {
@@ -1037,7 +1041,8 @@ int pt_scene_bytes(pt_ctx* c, uint64_t* nodeBytes, uint64_t* triangleBytes, uint
 // Tuning hook.  key 0: pipeline (0 megakernel, 1 wavefront); 1: megakernel traversal-phase exit
 // threshold in 64ths of the live lanes; 2: wavefront refill threshold (idle lanes); 3: wavefront
 // iterations between read-backs of the live-ray count; 4: traverse grid size in blocks (0 = auto);
-// 5: megakernel hit-shading threshold in 64ths of the live lanes; 6: longest-tile-first launch order on/off.
+// 5: megakernel hit-shading threshold in 64ths of the live lanes; 6: longest-tile-first launch order on/off;
+// 7: samples of a tile traced by one megakernel block.
 int pt_debug_set_tuning(pt_ctx* c, int key, int value)
 {
     if (!c) return fail(PT_ERR_INVALID, "null context");
@@ -1069,6 +1074,10 @@ int pt_debug_set_tuning(pt_ctx* c, int key, int value)
     case 6:
         if (value != 0 && value != 1) return fail(PT_ERR_INVALID, "tile ordering must be 0 or 1");
         c->tileOrdering = value != 0;
+        return PT_OK;
+    case 7:
+        if (value < 1 || value > 65536) return fail(PT_ERR_INVALID, "samples per block must be 1..65536");
+        c->samplesPerBlock = (uint32_t)value;
         return PT_OK;
     default: return fail(PT_ERR_INVALID, "unknown tuning key");
     }
