@@ -268,6 +268,11 @@ int pt_get_stats(pt_ctx* ctx, pt_stats* out);
 /* Milliseconds spent by the device in the most recent dispatch (HIP events on the context's
  * stream); synchronises. */
 int pt_last_dispatch_ms(pt_ctx* ctx, float* ms_out);
+/* The same for the two kernels of the most recent megakernel launch, each on its own: the trace
+ * kernel (renderKernel) and the pass that folds its sample records into the images (resolveKernel).
+ * A dispatch that was split into several launches reports its last one.  Measurement only; the
+ * reference has no counterpart (it times nothing). */
+int pt_last_kernel_ms(pt_ctx* ctx, float* trace_ms_out, float* resolve_ms_out);
 /* Device-side sizes of the packed scene, for bandwidth accounting. */
 int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, uint64_t* shading_bytes);
 
@@ -278,7 +283,9 @@ int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, 
  * 4: traverse grid size in blocks (0 = sized from the occupancy query); 5: megakernel hit-shading
  * threshold in 64ths of the live lanes (default 16): hits wait until that share of the wave holds one;
  * 6: longest-tile-first launch order from the previous launch's per-tile cost (default 1); 7: samples
- * of a tile that one megakernel block traces (default 65536: the whole launch; smaller values were slower). */
+ * of a tile that one megakernel block traces (default 65536: the whole launch; smaller values were slower);
+ * 8: budget of the megakernel's sample buffer in MiB (48 bytes per sample and pixel; a dispatch is cut
+ * into launches that fit; default 8192). */
 int pt_debug_set_tuning(pt_ctx* ctx, int key, int value);
 
 /* Profiling hook, not part of the drop-in surface (no counterpart in the reference): wave-level

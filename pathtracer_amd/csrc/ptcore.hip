@@ -82,6 +82,8 @@ struct pt_ctx {
     hipStream_t ownStream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t evStart = nullptr, evStop = nullptr;
+    hipEvent_t evTrace0 = nullptr, evTrace1 = nullptr, evResolve1 = nullptr;  // around the last megakernel launch
+    bool kernelTimed = false;
     bool timed = false;
 
     // caller-supplied reference-layout buffers (copied at upload, like glBufferData)
@@ -447,6 +449,7 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
         HIP_TRY(hipMemsetAsync(c->dTileCost.ptr, 0, tiles * 4, c->stream));  // blocks add their lifetimes
         c->tileCostValid = true;
         const dim3 grid((unsigned)(tiles * parts)), block(kMegaThreads);
+        HIP_TRY(hipEventRecord(c->evTrace0, c->stream));
         // the LDS stack is sized in three steps: 8, 12 or 16 KB per wave
         const int stackClass = c->maxDepth <= 32 ? 0 : (c->maxDepth <= 48 ? 1 : 2);
         if (counted) {
@@ -464,8 +467,11 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
             else
                 hipLaunchKernelGGL((renderKernel<32, false>), grid, block, 0, c->stream, P, S, img, ctr);
         }
+        HIP_TRY(hipEventRecord(c->evTrace1, c->stream));
         hipLaunchKernelGGL(resolveKernel, dim3((unsigned)((P.pixels + 255) / 256)), dim3(256), 0, c->stream, P, img);
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->evResolve1, c->stream));
+        c->kernelTimed = true;
     } else {
         int rc2 = wavefrontDispatch(c, P, S, img, ctr, counted);
         if (rc2 != PT_OK) return rc2;
@@ -529,6 +535,9 @@ int pt_create(int device, int width, int height, pt_ctx** out)
     c->stream = c->ownStream;
     HIP_TRY(hipEventCreate(&c->evStart));
     HIP_TRY(hipEventCreate(&c->evStop));
+    HIP_TRY(hipEventCreate(&c->evTrace0));
+    HIP_TRY(hipEventCreate(&c->evTrace1));
+    HIP_TRY(hipEventCreate(&c->evResolve1));
     const size_t imageBytes = (size_t)width * height * sizeof(float4);
     for (int i = 0; i < 3; i++) {
         HIP_TRY(c->dImages[i].ensure(imageBytes));
@@ -558,6 +567,9 @@ void pt_destroy(pt_ctx* c)
     if (c->hCtrl) (void)hipHostFree(c->hCtrl);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
+    if (c->evTrace0) (void)hipEventDestroy(c->evTrace0);
+    if (c->evTrace1) (void)hipEventDestroy(c->evTrace1);
+    if (c->evResolve1) (void)hipEventDestroy(c->evResolve1);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
 }
@@ -1029,6 +1041,17 @@ int pt_last_dispatch_ms(pt_ctx* c, float* msOut)
     return PT_OK;
 }
 
+int pt_last_kernel_ms(pt_ctx* c, float* traceMs, float* resolveMs)
+{
+    if (!c || !traceMs || !resolveMs) return fail(PT_ERR_INVALID, "null argument");
+    if (!c->kernelTimed) return fail(PT_ERR_STATE, "no megakernel launch yet");
+    DeviceGuard guard(c->device);
+    HIP_TRY(hipEventSynchronize(c->evResolve1));
+    HIP_TRY(hipEventElapsedTime(traceMs, c->evTrace0, c->evTrace1));
+    HIP_TRY(hipEventElapsedTime(resolveMs, c->evTrace1, c->evResolve1));
+    return PT_OK;
+}
+
 int pt_scene_bytes(pt_ctx* c, uint64_t* nodeBytes, uint64_t* triangleBytes, uint64_t* shadingBytes)
 {
     if (!c) return fail(PT_ERR_INVALID, "null context");
@@ -1042,7 +1065,8 @@ int pt_scene_bytes(pt_ctx* c, uint64_t* nodeBytes, uint64_t* triangleBytes, uint
 // threshold in 64ths of the live lanes; 2: wavefront refill threshold (idle lanes); 3: wavefront
 // iterations between read-backs of the live-ray count; 4: traverse grid size in blocks (0 = auto);
 // 5: megakernel hit-shading threshold in 64ths of the live lanes; 6: longest-tile-first launch order on/off;
-// 7: samples of a tile traced by one megakernel block.
+// 7: samples of a tile traced by one megakernel block; 8: sample-buffer budget in MiB (a dispatch is
+// cut into launches whose sample records fit).
 int pt_debug_set_tuning(pt_ctx* c, int key, int value)
 {
     if (!c) return fail(PT_ERR_INVALID, "null context");
@@ -1078,6 +1102,10 @@ int pt_debug_set_tuning(pt_ctx* c, int key, int value)
     case 7:
         if (value < 1 || value > 65536) return fail(PT_ERR_INVALID, "samples per block must be 1..65536");
         c->samplesPerBlock = (uint32_t)value;
+        return PT_OK;
+    case 8:
+        if (value < 1) return fail(PT_ERR_INVALID, "sample budget must be >= 1 MiB");
+        c->sampleBudgetBytes = (uint64_t)value << 20;
         return PT_OK;
     default: return fail(PT_ERR_INVALID, "unknown tuning key");
     }

@@ -121,6 +121,7 @@ SYMBOLS = {
     "pt_read_image_rgb": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "pt_get_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Stats)]),
     "pt_last_dispatch_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
+    "pt_last_kernel_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
     "pt_scene_bytes": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64),
                                       ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "pt_debug_set_tuning": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),

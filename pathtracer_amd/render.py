@@ -20,8 +20,11 @@ import numpy as np
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--scene", default="BunnyDielectric",
-                    help="BunnyDielectric | BunnyMetallic | BunnyGlass | BunnyClearcoat | DragonGlass | TorusMixed | "
-                         "SphereField")
+                    help="one of the reference application's scenes (AreaLight, Fireplace, Mill, Sponza, SponzaReduced, "
+                         "Bunny|Dragon + Dielectric|Metallic|Glass|Clearcoat), or TorusMixed, SphereField")
+    ap.add_argument("--content", default=None,
+                    help="the application's Content directory; models found there are read instead of the meshes "
+                         "committed with this package")
     ap.add_argument("--gltf", default=None, action="append",
                     help=".gltf / .glb file (or a tests/golden/scenes/*.npz fixture) to render instead of a recipe "
                          "(repeatable: models are added in order)")
@@ -46,7 +49,7 @@ def main(argv=None):
     args = ap.parse_args(argv)
 
     import torch
-    from . import image_io, scenes
+    from . import image_io, recipes, scenes
     from . import renderer as R
     from .distributed import ShardedRenderer
 
@@ -75,6 +78,11 @@ def main(argv=None):
         args.scene = ",".join(os.path.basename(x) for x in args.gltf)
     elif args.scene == "SphereField":
         meshes, mats = scenes.sphere_field()
+    elif args.scene in recipes.REFERENCE_SCENES:
+        meshes, mats, textures, notes = recipes.load_scene(args.scene, args.content, args.max_texture_size)
+        for note in notes:
+            if rank == 0:
+                print(note, file=sys.stderr)
     else:
         meshes, mats = scenes.flatten(scenes.recipe(args.scene))
     if args.hdri:

@@ -125,10 +125,10 @@ class Renderer:
         fn = self._lib.pt_dispatch_counted if counted else self._lib.pt_dispatch
         check(fn(self._h, int(frame_first), int(frame_count), int(frame_stride)))
 
-    TUNING_KEYS = {"pipeline": 0, "trav_exit": 1, "refill_min": 2, "check_every": 3, "traverse_blocks": 4, "hit_min": 5, "tile_order": 6, "samples_per_block": 7}
+    TUNING_KEYS = {"pipeline": 0, "trav_exit": 1, "refill_min": 2, "check_every": 3, "traverse_blocks": 4, "hit_min": 5, "tile_order": 6, "samples_per_block": 7, "sample_budget_mib": 8}
 
     def set_tuning(self, **kw):
-        """pipeline=0|1 (megakernel|wavefront), trav_exit, refill_min, check_every, traverse_blocks, hit_min, tile_order, samples_per_block."""
+        """pipeline=0|1 (megakernel|wavefront), trav_exit, refill_min, check_every, traverse_blocks, hit_min, tile_order, samples_per_block, sample_budget_mib."""
         for k, v in kw.items():
             check(self._lib.pt_debug_set_tuning(self._h, self.TUNING_KEYS[k], int(v)))
 
@@ -173,6 +173,12 @@ class Renderer:
         ms = ctypes.c_float()
         check(self._lib.pt_last_dispatch_ms(self._h, ctypes.byref(ms)))
         return ms.value
+
+    def last_kernel_ms(self):
+        """(trace kernel ms, resolve kernel ms) of the most recent megakernel launch."""
+        a, b = ctypes.c_float(), ctypes.c_float()
+        check(self._lib.pt_last_kernel_ms(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     def scene_bytes(self):
         a, b, c = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
