@@ -220,6 +220,65 @@ def test_multi_frame_launch_equals_frame_by_frame(pipeline):
         assert a.tobytes() == b.tobytes()
 
 
+def test_launch_splitting_does_not_change_a_bit():
+    """The megakernel's sample buffer has a budget: a dispatch that exceeds it runs as several
+    launches.  A tile's samples can also be spread over several blocks.  Neither may change the
+    images, and the oracle's frame-by-frame running mean is the reference for all of them."""
+    o, g = _pair("TorusMixed", 96, 80)
+    p = R.default_params(96, 80)
+    g.set_params(p)
+    cpu = o.render(p, 96, 80, 3, 11, 2)  # FrameCount 3, 5, ..., 23
+    frame_bytes_mib = 1  # 96*80*48 B = 0.35 MiB per frame: a 1 MiB budget holds 2 frames per launch
+    for tuning in (dict(), dict(sample_budget_mib=frame_bytes_mib), dict(samples_per_block=4),
+                   dict(sample_budget_mib=frame_bytes_mib, samples_per_block=1), dict(tile_order=0)):
+        g.set_tuning(**dict(dict(sample_budget_mib=8192, samples_per_block=65536, tile_order=1), **tuning))
+        g.clear()
+        g.dispatch(3, 11, 2)
+        for k in range(3):
+            assert g.read_image(k).tobytes() == cpu[k].tobytes(), (tuning, k)
+
+
+def test_full_hd_launch_properties():
+    """At the benchmark's image size the oracle is too slow to render every pixel, so the full-size
+    launch is checked through properties: one 12-frame dispatch equals 12 one-frame dispatches bit for
+    bit, sum mode over disjoint FrameCount sets adds up to the sum over their union (the multi-GPU
+    sharding identity, exact up to float summation order), and three bands of rows equal the oracle."""
+    o, g = _pair("BunnyGlass", 1920, 1080)
+    p = R.default_params(1920, 1080)
+    p.max_bounces = 8
+    g.set_params(p)
+    g.clear()
+    g.dispatch(1, 12, 1)
+    whole = [g.read_image(k) for k in range(3)]
+    g.clear()
+    for f in range(1, 13):
+        g.dispatch(f, 1, 1)
+    for k in range(3):
+        assert g.read_image(k).tobytes() == whole[k].tobytes()
+    # three 8-row bands against the oracle (FrameCount 1..3 keeps the CPU side to seconds)
+    g.clear()
+    g.dispatch(1, 3, 1)
+    gpu = [g.read_image(k) for k in range(3)]
+    for y0, y1 in ((0, 8), (536, 544), (1072, 1080)):
+        cpu = o.render(p, 1920, 1080, 1, 3, 1, rows=(y0, y1))
+        for k in range(3):
+            assert gpu[k][y0:y1].tobytes() == cpu[k][y0:y1].tobytes(), (y0, k)
+    # sharding identity in sum mode
+    p.accumulate_mode = 1
+    g.set_params(p)
+    parts = []
+    for rank in range(2):
+        g.clear()
+        g.dispatch(1 + rank, 6, 2)
+        parts.append(g.read_image(0).astype(np.float64))
+    g.clear()
+    g.dispatch(1, 12, 1)
+    union = g.read_image(0).astype(np.float64)
+    assert np.all(union[..., 3] == 12.0)
+    err = np.abs(parts[0] + parts[1] - union)
+    assert np.all(err <= 1e-5 * np.maximum(1.0, np.abs(union)))
+
+
 @PIPELINES
 def test_sum_mode_and_scale(pipeline):
     o, g = _pair("TorusMixed", 64, 48, pipeline=pipeline)
