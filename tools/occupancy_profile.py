@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Wave-occupancy profile of the megakernel on the benchmark workload (counting build)."""
+"""Wave-occupancy profile of the megakernel on the benchmark workload (counting build).
+    python tools/occupancy_profile.py [spp] [key=value tuning settings ...]"""
 import os
 import sys
 
@@ -21,6 +22,9 @@ g.upload_environment(work["hdri"], work["cache"])
 p = R.default_params(1920, 1080)
 p.max_bounces = 8
 g.set_params(p)
+tuning = dict(item.split("=") for item in sys.argv[2:])
+if tuning:
+    g.set_tuning(**{k: int(v) for k, v in tuning.items()})
 g.clear()
 g.dispatch(1, spp, 1, counted=True)
 g.synchronize()
