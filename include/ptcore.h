@@ -259,6 +259,12 @@ int pt_synchronize(pt_ctx* ctx);
 /* glGetTexImage(GL_RGBA, GL_FLOAT) (PathTracingRenderPass.cpp:89-99 reads GL_RGB): copies
  * width*height*4 floats to host memory; synchronises the stream. */
 int pt_read_image(pt_ctx* ctx, int which, float* rgba_out);
+/* The inverse of pt_read_image: replaces an accumulation image by width*height RGBA floats from the
+ * host, so that a progressive render can go on from saved images (continue with the FrameCount
+ * that follows the last one accumulated).  The reference keeps its accumulation only in GL textures
+ * and restarts at frame 1 after any change (PathTracingApplication.cpp:85-88,
+ * PathTracingRenderPass.cpp:62-64); this entry point has no counterpart there.  Synchronises. */
+int pt_write_image(pt_ctx* ctx, int which, const float* rgba);
 /* The same read-back in the reference's own layout: glGetTexImage(GL_RGB, GL_FLOAT) into
  * glm::vec3[width*height] (PathTracingRenderPass.cpp:89-99), which is also the Float3 row-major
  * buffer the reference hands to its denoiser for colour, albedo and normal (:101-155).  Copies

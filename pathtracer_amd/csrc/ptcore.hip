@@ -997,6 +997,17 @@ int pt_read_image(pt_ctx* c, int which, float* rgbaOut)
     return PT_OK;
 }
 
+int pt_write_image(pt_ctx* c, int which, const float* rgba)
+{
+    if (!c || !rgba) return fail(PT_ERR_INVALID, "null argument");
+    if (which < 0 || which > 2) return fail(PT_ERR_INVALID, "image index must be 0..2");
+    DeviceGuard guard(c->device);
+    const size_t imageBytes = (size_t)c->width * c->height * sizeof(float4);
+    HIP_TRY(hipMemcpyAsync(imagePtr(c, which), rgba, imageBytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the caller's buffer is free again on return
+    return PT_OK;
+}
+
 int pt_read_image_rgb(pt_ctx* c, int which, float* rgbOut)
 {
     if (!c || !rgbOut) return fail(PT_ERR_INVALID, "null argument");

@@ -118,6 +118,7 @@ SYMBOLS = {
     "pt_scale_images": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float]),
     "pt_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
     "pt_read_image": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "pt_write_image": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "pt_read_image_rgb": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "pt_get_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Stats)]),
     "pt_last_dispatch_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),

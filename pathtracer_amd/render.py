@@ -45,6 +45,8 @@ def main(argv=None):
     ap.add_argument("--exr", default=None)
     ap.add_argument("--pfm", default=None)
     ap.add_argument("--aov-prefix", default=None, help="also write <prefix>albedo.png and <prefix>normal.png")
+    ap.add_argument("--checkpoint", default=None, help="save the accumulation images and the next FrameCount here (.npz)")
+    ap.add_argument("--resume", default=None, help="continue from a --checkpoint file up to --spp (one GPU)")
     ap.add_argument("--device", type=int, default=None)
     args = ap.parse_args(argv)
 
@@ -109,14 +111,22 @@ def main(argv=None):
     p.focal_length = args.focal_length
     p.anti_aliasing_enabled = 0 if args.no_aa else 1
     sr.set_params(p)
-    sr.clear()
+    if (args.resume or args.checkpoint) and world > 1:
+        raise SystemExit("--checkpoint / --resume work on one GPU (ranks hold partial sums)")
+    first = 1
+    if args.resume:
+        first = g.load_checkpoint(args.resume)
+    else:
+        sr.clear()
     t0 = time.time()
-    per_rank = (args.spp - rank + world - 1) // world  # FrameCount rank+1, rank+1+world, ... <= spp
+    per_rank = (args.spp - (first - 1) - rank + world - 1) // world  # FrameCount first+rank, first+rank+world, ... <= spp
     if per_rank > 0:
-        g.dispatch(1 + rank, per_rank, world)
+        g.dispatch(first + rank, per_rank, world)
     sr.reduce()
     images = sr.resolve(args.spp).cpu().numpy()
     t_render = time.time() - t0
+    if args.checkpoint:
+        g.save_checkpoint(args.checkpoint, args.spp + 1)
     if rank == 0:
         rad, alb, nor = images[0], images[1], images[2]
         image_io.write_png(args.out, image_io.tonemap(rad[..., :3], args.exposure))

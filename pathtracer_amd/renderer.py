@@ -158,6 +158,27 @@ class Renderer:
         check(self._lib.pt_read_image(self._h, int(which), _ptr(out)))
         return out
 
+    def write_image(self, which, rgba):
+        a = np.ascontiguousarray(rgba, dtype=np.float32)
+        if a.shape != (self.height, self.width, 4):
+            raise ValueError(f"image must be ({self.height}, {self.width}, 4)")
+        check(self._lib.pt_write_image(self._h, int(which), _ptr(a)))
+
+    def save_checkpoint(self, path, next_frame):
+        """Accumulation images + the FrameCount to go on with, as an .npz (a progressive render
+        continues bit-identically from it: see load_checkpoint)."""
+        np.savez(path, radiance=self.read_image(0), albedo=self.read_image(1), normal=self.read_image(2),
+                 next_frame=np.uint32(next_frame), size=np.array([self.width, self.height], np.int32))
+
+    def load_checkpoint(self, path):
+        """-> the FrameCount to dispatch next.  The scene and parameters are the caller's to restore."""
+        with np.load(path if str(path).endswith(".npz") else str(path) + ".npz", allow_pickle=False) as z:
+            if tuple(z["size"]) != (self.width, self.height):
+                raise ValueError(f"checkpoint is {tuple(z['size'])}, the renderer {self.width}x{self.height}")
+            for which, name in enumerate(("radiance", "albedo", "normal")):
+                self.write_image(which, z[name])
+            return int(z["next_frame"])
+
     def read_image_rgb(self, which):
         """(height, width, 3) float32: the layout the reference reads back for its denoiser."""
         out = np.empty((self.height, self.width, 3), np.float32)

@@ -426,3 +426,26 @@ def test_error_behaviour():
     pp = R.default_params(64, 64)
     with pytest.raises(L.PtError):
         g.set_params(pp)  # FrameDimensions mismatch
+
+
+def test_checkpoint_resumes_bit_identically(tmp_path):
+    """Images saved after FrameCount 1..4 and restored into a fresh context, then FrameCount 5..8:
+    the same bits as FrameCount 1..8 in one go."""
+    _, g = _pair("TorusMixed", 72, 40)
+    p = R.default_params(72, 40)
+    g.set_params(p)
+    g.clear()
+    g.dispatch(1, 8, 1)
+    whole = [g.read_image(k) for k in range(3)]
+    g.clear()
+    g.dispatch(1, 4, 1)
+    g.save_checkpoint(tmp_path / "half", 5)
+    _, h = _pair("TorusMixed", 72, 40)
+    h.set_params(p)
+    nxt = h.load_checkpoint(tmp_path / "half")
+    assert nxt == 5
+    h.dispatch(nxt, 4, 1)
+    for k in range(3):
+        assert h.read_image(k).tobytes() == whole[k].tobytes()
+    with pytest.raises(ValueError):
+        R.Renderer(64, 40).load_checkpoint(tmp_path / "half")
