@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--bvh", choices=["host", "device"], default="host",
                     help="host: the reference's sweep-SAH builder (bit-identical tree); device: GPU linear BVH")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tuning", default="", help="scheduler settings for A/B runs: key=value,key=value (Renderer.set_tuning)")
     args = ap.parse_args()
     if args.subdivide is None:
         args.subdivide = DEFAULT_SUBDIVIDE if args.copies == 1 else 0
@@ -144,6 +145,8 @@ def main():
     if work["side"] > 1:  # pull the camera back and up so the whole grid is in view
         R.set_camera(params, (-2.5 - 1.1 * work["side"], 1.0 + 0.8 * work["side"], 0.0), (0.0, 0.0, 0.0), W, H)
     sr.set_params(params)
+    if args.tuning:
+        g.set_tuning(**{k: int(v) for k, v in (item.split("=") for item in args.tuning.split(","))})
 
     # traversal statistics of one step (untimed, counting build of the same kernel, same frames)
     sr.clear()

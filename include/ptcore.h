@@ -291,7 +291,8 @@ int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, 
  * 6: longest-tile-first launch order from the previous launch's per-tile cost (default 1); 7: samples
  * of a tile that one megakernel block traces (default 65536: the whole launch; smaller values were slower);
  * 8: budget of the megakernel's sample buffer in MiB (48 bytes per sample and pixel; a dispatch is cut
- * into launches that fit; default 8192). */
+ * into launches that fit; default 8192); 9: trees deeper than 32 levels keep their whole traversal stack
+ * in LDS (1) instead of 32 entries there and the rest in lane-private memory (0, the default). */
 int pt_debug_set_tuning(pt_ctx* ctx, int key, int value);
 
 /* Profiling hook, not part of the drop-in surface (no counterpart in the reference): wave-level

@@ -113,8 +113,24 @@ PT_DEV void beginQuery(Query& q, int rootRef, v3 ro, v3 rd, bool isShadow)
 // triangle half back until several lanes of the wave have a leaf was measured: every threshold
 // above one lane is slower, the lanes that wait cost more than the fuller triangle steps save.)
 // `stack` points at this thread's column of the block's LDS stack (entries STRIDE words apart).
-template <bool COUNT, int STRIDE = kBlockThreads>
-PT_DEV bool queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc)
+// With LDS_DEPTH > 0 only the first LDS_DEPTH entries live there and deeper ones go to `deep`, an
+// array in the lane's private memory: deep trees then cost no more LDS (and no fewer resident
+// waves) than shallow ones, and the entries past LDS_DEPTH are touched by very few rays.
+template <int STRIDE, int LDS_DEPTH>
+PT_DEV void stackPut(int* stack, int* deep, int i, int v)
+{
+    if (LDS_DEPTH == 0 || i < LDS_DEPTH) stack[i * STRIDE] = v;
+    else deep[i - LDS_DEPTH] = v;
+}
+template <int STRIDE, int LDS_DEPTH>
+PT_DEV int stackGet(const int* stack, const int* deep, int i)
+{
+    if (LDS_DEPTH == 0 || i < LDS_DEPTH) return stack[i * STRIDE];
+    return deep[i - LDS_DEPTH];
+}
+
+template <bool COUNT, int STRIDE = kBlockThreads, int LDS_DEPTH = 0>
+PT_DEV bool queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc, int* deep = nullptr)
 {
     const bool hasNode = q.cur > 0;
     const bool doTri = q.leafPos < q.leafEnd;
@@ -139,7 +155,7 @@ PT_DEV bool queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc)
         const bool both = hl && hr;
         const bool leftFirst = dl < dr;  // intersection.glsl:169-180
         if (both) {  // postpone the far child
-            if (q.sp > 0) stack[(q.sp - 1) * STRIDE] = q.top;
+            if (q.sp > 0) stackPut<STRIDE, LDS_DEPTH>(stack, deep, q.sp - 1, q.top);
             q.top = leftFirst ? right : left;
             q.sp++;
             if (COUNT) sc.maxStack = (unsigned)q.sp > sc.maxStack ? (unsigned)q.sp : sc.maxStack;
@@ -173,7 +189,7 @@ PT_DEV bool queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc)
     if (pop) {  // both children missed: next sub-tree off the stack
         q.cur = q.sp > 0 ? q.top : 0;
         q.sp = q.sp > 0 ? q.sp - 1 : 0;
-        if (q.sp > 0) q.top = stack[(q.sp - 1) * STRIDE];
+        if (q.sp > 0) q.top = stackGet<STRIDE, LDS_DEPTH>(stack, deep, q.sp - 1);
     }
     if (q.cur < 0 && q.leafPos == q.leafEnd) {  // park the leaf `cur` refers to, walk on
         const unsigned bits = ~(unsigned)q.cur;
@@ -181,7 +197,7 @@ PT_DEV bool queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc)
         q.leafEnd = q.leafPos + (bits & 7u) + 1u;
         q.cur = q.sp > 0 ? q.top : 0;
         q.sp = q.sp > 0 ? q.sp - 1 : 0;
-        if (q.sp > 0) q.top = stack[(q.sp - 1) * STRIDE];
+        if (q.sp > 0) q.top = stackGet<STRIDE, LDS_DEPTH>(stack, deep, q.sp - 1);
     }
     return finished || (q.cur == 0 && q.leafPos == q.leafEnd);
 }
@@ -404,11 +420,13 @@ PT_DEV unsigned laneRank(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
-template <int STACK, bool COUNT>
+// STACK entries of traversal stack per lane in LDS, DEEP more in private memory (0: none).
+template <int STACK, int DEEP, bool COUNT>
 __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(DevParams P, DevScene S, Images img, DevCounters* counters)
 {
     static_assert(kMegaThreads == 64, "one wave per block: the sample pool below is wave-wide");
     __shared__ int s_stack[STACK * kMegaThreads];
+    int deepStack[DEEP > 0 ? DEEP : 1];
     __shared__ unsigned s_pixel[64];  // the tile's pixels that lie inside the image, compacted
     const unsigned lane = threadIdx.x;
     int* stack = s_stack + lane;
@@ -566,7 +584,7 @@ __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(
                 prof[5] += (unsigned)__popcll(tri);
             }
             if (mode == kModeTrav) {
-                if (queryStep<COUNT, kMegaThreads>(S, q, stack, sc)) {
+                if (queryStep<COUNT, kMegaThreads, (DEEP > 0 ? STACK : 0)>(S, q, stack, sc, deepStack)) {
                     if (q.isShadow) {
                         if (q.bestPrim < 0) ps.radiance = ps.radiance + pending;  // unoccluded
                         if (hasExt) {

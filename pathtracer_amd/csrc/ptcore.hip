@@ -112,6 +112,7 @@ struct pt_ctx {
     // finished samples of one launch, 48 B per (sample, pixel); resolved into the images after the launch
     DeviceBuffer dSamples;
     uint64_t sampleBudgetBytes = 8ull << 30;
+    bool deepStackInLds = false;  // trees deeper than 32 levels: whole stack in LDS (12/16 KB per wave)
     uint32_t samplesPerBlock = 65536;
     size_t waveTimeCount = 0;
     // geometry built on the device (pt_build_bvh_device): the tree in the reference's layouts, kept for
@@ -450,23 +451,20 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
         c->tileCostValid = true;
         const dim3 grid((unsigned)(tiles * parts)), block(kMegaThreads);
         HIP_TRY(hipEventRecord(c->evTrace0, c->stream));
-        // the LDS stack is sized in three steps: 8, 12 or 16 KB per wave
-        const int stackClass = c->maxDepth <= 32 ? 0 : (c->maxDepth <= 48 ? 1 : 2);
-        if (counted) {
-            if (stackClass == 2)
-                hipLaunchKernelGGL((renderKernel<64, true>), grid, block, 0, c->stream, P, S, img, ctr);
-            else if (stackClass == 1)
-                hipLaunchKernelGGL((renderKernel<48, true>), grid, block, 0, c->stream, P, S, img, ctr);
-            else
-                hipLaunchKernelGGL((renderKernel<32, true>), grid, block, 0, c->stream, P, S, img, ctr);
-        } else {
-            if (stackClass == 2)
-                hipLaunchKernelGGL((renderKernel<64, false>), grid, block, 0, c->stream, P, S, img, ctr);
-            else if (stackClass == 1)
-                hipLaunchKernelGGL((renderKernel<48, false>), grid, block, 0, c->stream, P, S, img, ctr);
-            else
-                hipLaunchKernelGGL((renderKernel<32, false>), grid, block, 0, c->stream, P, S, img, ctr);
-        }
+        // Trees up to 32 levels deep keep the whole traversal stack in LDS (8 KB per wave).  Deeper
+        // ones keep 32 entries there and the rest in private memory, or (deepStackInLds, for A/B) get
+        // a 12 or 16 KB LDS stack at the price of resident waves.
+        const int stackClass = c->maxDepth <= 32 ? 0 : (!c->deepStackInLds ? 3 : (c->maxDepth <= 48 ? 1 : 2));
+#define PT_LAUNCH_TRACE(COUNTED)                                                                                         \
+    do {                                                                                                                 \
+        if (stackClass == 3) hipLaunchKernelGGL((renderKernel<32, 32, COUNTED>), grid, block, 0, c->stream, P, S, img, ctr);      \
+        else if (stackClass == 2) hipLaunchKernelGGL((renderKernel<64, 0, COUNTED>), grid, block, 0, c->stream, P, S, img, ctr); \
+        else if (stackClass == 1) hipLaunchKernelGGL((renderKernel<48, 0, COUNTED>), grid, block, 0, c->stream, P, S, img, ctr); \
+        else hipLaunchKernelGGL((renderKernel<32, 0, COUNTED>), grid, block, 0, c->stream, P, S, img, ctr);                      \
+    } while (0)
+        if (counted) PT_LAUNCH_TRACE(true);
+        else PT_LAUNCH_TRACE(false);
+#undef PT_LAUNCH_TRACE
         HIP_TRY(hipEventRecord(c->evTrace1, c->stream));
         hipLaunchKernelGGL(resolveKernel, dim3((unsigned)((P.pixels + 255) / 256)), dim3(256), 0, c->stream, P, img);
         HIP_TRY(hipGetLastError());
@@ -1077,7 +1075,8 @@ int pt_scene_bytes(pt_ctx* c, uint64_t* nodeBytes, uint64_t* triangleBytes, uint
 // iterations between read-backs of the live-ray count; 4: traverse grid size in blocks (0 = auto);
 // 5: megakernel hit-shading threshold in 64ths of the live lanes; 6: longest-tile-first launch order on/off;
 // 7: samples of a tile traced by one megakernel block; 8: sample-buffer budget in MiB (a dispatch is
-// cut into launches whose sample records fit).
+// cut into launches whose sample records fit); 9: trees deeper than 32 levels keep their whole traversal
+// stack in LDS (1) instead of 32 entries there and the rest in private memory (0, the default).
 int pt_debug_set_tuning(pt_ctx* c, int key, int value)
 {
     if (!c) return fail(PT_ERR_INVALID, "null context");
@@ -1113,6 +1112,10 @@ int pt_debug_set_tuning(pt_ctx* c, int key, int value)
     case 7:
         if (value < 1 || value > 65536) return fail(PT_ERR_INVALID, "samples per block must be 1..65536");
         c->samplesPerBlock = (uint32_t)value;
+        return PT_OK;
+    case 9:
+        if (value != 0 && value != 1) return fail(PT_ERR_INVALID, "deep_stack_in_lds must be 0 or 1");
+        c->deepStackInLds = value != 0;
         return PT_OK;
     case 8:
         if (value < 1) return fail(PT_ERR_INVALID, "sample budget must be >= 1 MiB");

@@ -449,3 +449,68 @@ def test_checkpoint_resumes_bit_identically(tmp_path):
         assert h.read_image(k).tobytes() == whole[k].tobytes()
     with pytest.raises(ValueError):
         R.Renderer(64, 40).load_checkpoint(tmp_path / "half")
+
+
+def _chain_tree(levels):
+    """levels + 1 big triangles facing -x at x = 0, 0.1, ..., each in a leaf of its own, under a tree
+    that is one long chain: interior node j holds the farthest remaining triangle as its left leaf
+    and everything nearer below its right child.  A ray travelling +x descends to the right and
+    postpones a leaf at every level, so its traversal stack grows to `levels` entries."""
+    verts, idx = [], []
+    for k in range(levels + 1):
+        x = 0.1 * k
+        verts += [[x, -3, -3, -1, 0, 0, 0, 0], [x, -3, 3, -1, 0, 0, 0, 1], [x, 3, -3, -1, 0, 0, 1, 0]]
+        idx += [3 * k, 3 * k + 1, 3 * k + 2]
+    prims = R.assemble_primitives(np.array(verts, np.float32), np.array(idx, np.uint32), 0)
+    nodes = np.zeros((2 * levels + 2, 10), np.int32)
+    boxes = nodes.view(np.float32)
+
+    def leaf(node, tri):
+        nodes[node, 2], nodes[node, 3] = 1, tri
+        boxes[node, 4:7] = (0.1 * tri, -3, -3)
+        boxes[node, 7:10] = (0.1 * tri, 3, 3)
+
+    for j in range(levels):
+        me = 1 + 2 * j
+        nodes[me, 0] = me + 1                                       # left: leaf of triangle levels - j
+        nodes[me, 1] = me + 2 if j + 1 < levels else 1 + 2 * levels  # right: the rest, or the last leaf
+        boxes[me, 4:7] = (0.0, -3, -3)
+        boxes[me, 7:10] = (np.float32(0.1 * (levels - j)), 3, 3)
+        leaf(me + 1, levels - j)
+    leaf(1 + 2 * levels, 0)
+    return nodes.view(np.float32), prims
+
+
+@PIPELINES
+def test_traversal_stack_beyond_32_entries(pipeline):
+    """Trees deeper than 32 levels keep 32 stack entries in LDS and the rest in private memory.  A chain
+    tree drives the stack to 40 entries; the image must equal the one traced through the sweep-SAH tree
+    of the same triangles and the one traced with the whole stack in LDS."""
+    levels = 40
+    nodes40, prims = _chain_tree(levels)
+    mats = np.array([scenes.material(albedo=(0.7, 0.6, 0.5), roughness=0.6)], dtype=scenes.MATERIAL_DTYPE)
+    hdri, cache = environment(256, 128)
+    images = {}
+    sorted_prims, sah_nodes = R.build_bvh_sah(prims, 4)
+    for name, (n40, p100, tuning) in {
+        "chain": (nodes40, prims, dict(deep_stack_in_lds=0)),
+        "chain-lds": (nodes40, prims, dict(deep_stack_in_lds=1)),
+        "sah": (sah_nodes, sorted_prims, dict(deep_stack_in_lds=0)),
+    }.items():
+        g = R.Renderer(96, 64)
+        g.set_tuning(pipeline=pipeline, **tuning)
+        g.upload_nodes(R.align_nodes(n40))
+        g.upload_primitives(R.align_primitives(p100))
+        g.upload_materials(mats)
+        g.upload_environment(hdri, cache)
+        p = R.default_params(96, 64)
+        g.set_params(p)
+        g.clear()
+        g.dispatch(1, 3, 1, counted=True)
+        images[name] = [g.read_image(k) for k in range(3)]
+        if name.startswith("chain"):
+            assert g.stats().max_stack_depth >= levels, g.stats().max_stack_depth
+    for k in range(3):
+        assert images["chain"][k].tobytes() == images["chain-lds"][k].tobytes()
+        assert images["chain"][k].tobytes() == images["sah"][k].tobytes()
+    assert np.any(images["chain"][0][..., :3] > 0)
