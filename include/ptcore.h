@@ -288,8 +288,10 @@ int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, 
  * lanes (default 16); 3: wavefront iterations between read-backs of the live-ray count (default 2);
  * 4: traverse grid size in blocks (0 = sized from the occupancy query); 5: megakernel hit-shading
  * threshold in 64ths of the live lanes (default 16): hits wait until that share of the wave holds one;
- * 6: longest-tile-first launch order from the previous launch's per-tile cost (default 1); 7: samples
- * of a tile that one megakernel block traces (default 65536: the whole launch; smaller values were slower);
+ * 6: costliest-block-first launch order from the previous launch's per-tile cost (default 1); 7: tile
+ * split: a tile whose cost exceeds 1/value of the launch's lower bound (total cost / resident waves) has
+ * its samples spread over several blocks; 0 = one block per tile; -1 (default) = 2 for images with no
+ * more tiles than resident waves, else 1;
  * 8: budget of the megakernel's sample buffer in MiB (48 bytes per sample and pixel; a dispatch is cut
  * into launches that fit; default 8192); 9: trees deeper than 32 levels keep their whole traversal stack
  * in LDS (1) instead of 32 entries there and the rest in lane-private memory (0, the default). */

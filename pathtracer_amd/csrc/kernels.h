@@ -420,6 +420,62 @@ PT_DEV unsigned laneRank(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
+// ------------------------------------------------------------------ launch plan of the megakernel
+// From the ticks each tile's waves lived in the previous launch: how many blocks a tile's samples
+// are spread over, and the per-block cost the blocks are then sorted by.  With `slots` waves
+// resident on the chip the launch cannot end before total / slots ticks; a tile is split so that none
+// of its blocks costs more than 1/splitN of that bound, which adds at most splitN * slots blocks.
+// One block of 1024 threads.
+__global__ void planPartsKernel(const unsigned* __restrict__ cost, unsigned tiles, unsigned slots, unsigned splitN,
+                                unsigned maxParts, unsigned* __restrict__ parts, unsigned* __restrict__ key)
+{
+    __shared__ unsigned long long s_sum[1024];
+    unsigned long long sum = 0;
+    for (unsigned t = threadIdx.x; t < tiles; t += blockDim.x) sum += cost[t];
+    s_sum[threadIdx.x] = sum;
+    __syncthreads();
+    for (unsigned off = blockDim.x / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
+        __syncthreads();
+    }
+    const unsigned long long total = s_sum[0];
+    // largest cost a block may have: total / (slots * splitN), at least one tick
+    unsigned long long cap = total / ((unsigned long long)slots * splitN);
+    if (cap == 0) cap = 1;
+    for (unsigned t = threadIdx.x; t < tiles; t += blockDim.x) {
+        const unsigned long long c = cost[t];
+        unsigned long long n = (c + cap - 1) / cap;
+        n = n < 1 ? 1 : (n > maxParts ? maxParts : n);
+        parts[t] = (unsigned)n;
+        key[t] = (unsigned)(c / n);
+    }
+}
+
+// parts of the tiles in sorted order (input of the prefix sum that places their blocks)
+__global__ void gatherPartsKernel(const unsigned* __restrict__ order, const unsigned* __restrict__ parts, unsigned tiles,
+                                  unsigned* __restrict__ partsInOrder)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < tiles) partsInOrder[i] = parts[order[i]];
+}
+
+// block list: the blocks of the i-th tile in sorted order start at start[i]; a tile's `n` blocks take
+// equal shares of the launch's frameCount (< 65536) samples
+__global__ void fillBlocksKernel(const unsigned* __restrict__ order, const unsigned* __restrict__ partsInOrder,
+                                 const unsigned* __restrict__ start, unsigned tiles, unsigned capacity, unsigned frameCount,
+                                 unsigned* __restrict__ blockList, unsigned* __restrict__ blockCount)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= tiles) return;
+    const unsigned n = partsInOrder[i], first = start[i], tile = order[i];
+    for (unsigned p = 0; p < n && first + p < capacity; p++) {
+        const unsigned kBegin = p * frameCount / n, kEnd = (p + 1u) * frameCount / n;
+        blockList[2u * (first + p)] = tile;
+        blockList[2u * (first + p) + 1u] = (kBegin << 16) | (kEnd - kBegin);
+    }
+    if (i == tiles - 1) *blockCount = first + n < capacity ? first + n : capacity;
+}
+
 // STACK entries of traversal stack per lane in LDS, DEEP more in private memory (0: none).
 template <int STACK, int DEEP, bool COUNT>
 __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(DevParams P, DevScene S, Images img, DevCounters* counters)
@@ -433,15 +489,19 @@ __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(
 
     // Consecutive blocks go to different XCDs, so any block -> tile map that does not cluster
     // expensive tiles on one XCD keeps the eight of them equally loaded: row-major order without
-    // cost information, descending cost of the previous launch with it.
-    // A tile's samples are split into `parts` ranges of P.samplesPerBlock, one block each, so that no
-    // single wave carries a whole expensive tile.
-    const unsigned parts = (P.frameCount + P.samplesPerBlock - 1u) / P.samplesPerBlock;
-    const unsigned tileRank = blockIdx.x / parts, part = blockIdx.x - tileRank * parts;
-    const unsigned tile = P.tileOrder ? P.tileOrder[tileRank] : tileRank;
+    // cost information; with it, the block list the planning kernels below made from the previous
+    // launch's per-tile cost: costliest block first, an expensive tile's samples spread over several
+    // blocks so that no single wave carries the launch's critical path.
+    unsigned tile = blockIdx.x, kBegin = 0, kCount = P.frameCount;
+    if (P.blockList) {
+        // a block past the end of the list gets an empty sample range and falls through the loop below
+        const bool used = blockIdx.x < *P.blockCount;
+        const unsigned w0 = used ? P.blockList[2u * blockIdx.x] : 0u, w1 = used ? P.blockList[2u * blockIdx.x + 1u] : 0u;
+        tile = __builtin_amdgcn_readfirstlane(w0);
+        kBegin = __builtin_amdgcn_readfirstlane(w1 >> 16);
+        kCount = __builtin_amdgcn_readfirstlane(w1 & 0xffffu);
+    }
     const unsigned tileX = tile % P.tilesX, tileY = tile / P.tilesX;
-    const unsigned kBegin = part * P.samplesPerBlock;
-    const unsigned kCount = P.frameCount - kBegin < P.samplesPerBlock ? P.frameCount - kBegin : P.samplesPerBlock;
 
     // The wave owns its (pixel, sample) pairs as one pool, handed out in sample-major order:
     // a lane that finishes a path takes the next pair, whichever pixel it belongs to, so no lane
@@ -611,7 +671,7 @@ __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(
     const unsigned sRays = waveSum(nRays), sShadow = waveSum(nShadow), sHits = waveSum(nHits), sSamples = waveSum(nSamples);
     if (kMegaThreads == 64 && lane == 0) {
         const unsigned long long lived = wall_clock64() - waveStart;
-        atomicAdd(&P.tileCost[tile], lived > 0x0fffffffull ? 0x0fffffffu : (unsigned)lived);  // summed over the tile's blocks
+        if (kCount) atomicAdd(&P.tileCost[tile], lived > 0x0fffffffull ? 0x0fffffffu : (unsigned)lived);  // summed over the tile's blocks
     }
     if (lane == 0) {
         atomicAdd(&counters->raysClosest, (unsigned long long)sRays);

@@ -158,11 +158,11 @@ struct DevParams {
     int32_t rootRef;
     uint32_t tilesX, tilesY;
     uint32_t travExitNum;  // megakernel: leave the traversal phase below this many 64ths of the live lanes
-    const unsigned int* tileOrder;  // megakernel: block -> tile, longest tile first (null: identity)
+    const unsigned int* blockList;  // megakernel: per block {tile, first sample << 16 | samples}, costliest block first (null: block = tile)
+    const unsigned int* blockCount; // megakernel: entries of blockList in use (blocks past it exit at once)
     unsigned int* tileCost;         // megakernel: per tile, ticks its wave lived (input of the next launch's order)
     float* samples;                 // megakernel: finished samples, 3 x float4 per (sample, pixel), sample-major
     unsigned long long pixels;      // width * height
-    uint32_t samplesPerBlock;       // megakernel: samples of a tile that one block (wave) traces
     unsigned long long* waveTimes;  // counting build: per tile, wall-clock ticks at wave start and end (or null)
     uint32_t refillMin;    // wavefront: a wave refills from the ray queue once this many lanes are idle
     uint32_t hitMinNum;    // megakernel: shade hits once this many 64ths of the live lanes hold one

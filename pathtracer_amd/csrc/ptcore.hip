@@ -105,15 +105,18 @@ struct pt_ctx {
     DeviceBuffer dCounters;
     DeviceBuffer dRgbStaging;  // pt_read_image_rgb
     DeviceBuffer dWaveTimes;   // counting dispatches: start / end ticks per wave
-    // longest-tile-first launch order: ticks per tile of the previous launch, sorted descending
-    DeviceBuffer dTileCost, dTileCostSorted, dTileIds, dTileOrder, dTileSortTemp;
-    size_t tileCostTiles = 0, tileSortBytes = 0;
+    // launch plan of the megakernel from the ticks each tile's waves lived in the previous launch:
+    // blocks per tile, per-block cost (the sort key), tiles in descending key order, block list
+    DeviceBuffer dTileCost, dTileParts, dTileKey, dTileKeySorted, dTileIds, dTileOrder, dTileSortTemp;
+    DeviceBuffer dPartsInOrder, dBlockStart, dBlockList, dBlockCount, dScanTemp;
+    size_t tileCostTiles = 0, tileSortBytes = 0, scanBytes = 0, blockCapacity = 0;
     bool tileCostValid = false, tileOrdering = true;
+    int tileSplit = -1;  // no block may cost more than 1/tileSplit of the launch's lower bound (0: never split, -1: by image size)
+    uint32_t waveSlots = 4096;  // waves the chip holds at once (CUs x SIMDs x waves per SIMD)
     // finished samples of one launch, 48 B per (sample, pixel); resolved into the images after the launch
     DeviceBuffer dSamples;
     uint64_t sampleBudgetBytes = 8ull << 30;
     bool deepStackInLds = false;  // trees deeper than 32 levels: whole stack in LDS (12/16 KB per wave)
-    uint32_t samplesPerBlock = 65536;
     size_t waveTimeCount = 0;
     // geometry built on the device (pt_build_bvh_device): the tree in the reference's layouts, kept for
     // pt_download_bvh; dNodes / dTriangles / dShading are filled by the builder itself
@@ -402,54 +405,84 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
     P.refillMin = c->refillMin;
     P.hitMinNum = c->hitMinNum;
     P.waveTimes = nullptr;
-    if (counted && c->pipeline == 0) {
-        c->waveTimeCount = (size_t)P.tilesX * P.tilesY * ((frameCount + c->samplesPerBlock - 1) / c->samplesPerBlock);
-        HIP_TRY(c->dWaveTimes.ensure(c->waveTimeCount * 16));
-        HIP_TRY(hipMemsetAsync(c->dWaveTimes.ptr, 0, c->waveTimeCount * 16, c->stream));
-        P.waveTimes = (unsigned long long*)c->dWaveTimes.ptr;
-    }
     if (firstPart) HIP_TRY(hipMemsetAsync(c->dCounters.ptr, 0, sizeof(DevCounters), c->stream));
     DevCounters* ctr = (DevCounters*)c->dCounters.ptr;
     Images img{imagePtr(c, 0), imagePtr(c, 1), imagePtr(c, 2)};
     if (firstPart) HIP_TRY(hipEventRecord(c->evStart, c->stream));
     if (c->pipeline == 0) {
-        // Tiles are handed to the grid's blocks longest first: the cost of a tile (ticks its wave
-        // lived in the previous launch) varies by an order of magnitude, and a launch that reaches
-        // its expensive tiles last ends in a long, nearly empty tail.
+        // Blocks are launched costliest first: the cost of a tile (ticks its waves lived in the previous
+        // launch) varies by an order of magnitude, and a launch that reaches its expensive tiles last
+        // ends in a long, nearly empty tail.  A tile whose cost exceeds a fraction of the launch's
+        // lower bound has its samples spread over several blocks, so that one wave is never the
+        // critical path (small images, a few expensive tiles in a cheap frame).
         const size_t tiles = (size_t)P.tilesX * P.tilesY;
-        if (c->tileCostTiles != tiles) {
-            HIP_TRY(c->dTileCost.ensure(tiles * 4));
-            HIP_TRY(c->dTileCostSorted.ensure(tiles * 4));
-            HIP_TRY(c->dTileIds.ensure(tiles * 4));
-            HIP_TRY(c->dTileOrder.ensure(tiles * 4));
+        if (frameCount > 65535u) return fail(PT_ERR_INVALID, "a megakernel launch takes at most 65535 frames");
+        // Splitting costs a little (every block ends in a tail where its lanes run dry), so the cap is
+        // the lower bound itself, or half of it for images with no more tiles than wave slots (swept at
+        // 512 x 512, 720p and 1080p with 16 and 64 frames per launch), unless set by hand.
+        const unsigned split = c->tileSplit >= 0 ? (unsigned)c->tileSplit : (tiles <= c->waveSlots ? 2u : 1u);
+        const size_t capacity = tiles + (size_t)split * c->waveSlots;
+        if (c->tileCostTiles != tiles || c->blockCapacity != capacity) {
+            for (DeviceBuffer* b : {&c->dTileCost, &c->dTileParts, &c->dTileKey, &c->dTileKeySorted, &c->dTileIds, &c->dTileOrder,
+                                    &c->dPartsInOrder, &c->dBlockStart})
+                HIP_TRY(b->ensure(tiles * 4));
+            HIP_TRY(c->dBlockList.ensure(capacity * 8));
+            HIP_TRY(c->dBlockCount.ensure(4));
             std::vector<uint32_t> ids(tiles);
             for (size_t i = 0; i < tiles; i++) ids[i] = (uint32_t)i;
             HIP_TRY(hipMemcpyAsync(c->dTileIds.ptr, ids.data(), tiles * 4, hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));  // `ids` dies with this scope
             c->tileSortBytes = 0;
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, c->tileSortBytes, (const uint32_t*)c->dTileCost.ptr,
-                                                                 (uint32_t*)c->dTileCostSorted.ptr, (const uint32_t*)c->dTileIds.ptr,
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, c->tileSortBytes, (const uint32_t*)c->dTileKey.ptr,
+                                                                 (uint32_t*)c->dTileKeySorted.ptr, (const uint32_t*)c->dTileIds.ptr,
                                                                  (uint32_t*)c->dTileOrder.ptr, (int)tiles, 0, 32, c->stream));
             HIP_TRY(c->dTileSortTemp.ensure(c->tileSortBytes));
+            c->scanBytes = 0;
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, c->scanBytes, (const uint32_t*)c->dPartsInOrder.ptr,
+                                                     (uint32_t*)c->dBlockStart.ptr, (int)tiles, c->stream));
+            HIP_TRY(c->dScanTemp.ensure(c->scanBytes));
+            if (c->tileCostTiles != tiles) c->tileCostValid = false;
             c->tileCostTiles = tiles;
-            c->tileCostValid = false;
+            c->blockCapacity = capacity;
         }
         HIP_TRY(c->dSamples.ensure((size_t)frameCount * (size_t)c->width * c->height * 48u));
         P.samples = (float*)c->dSamples.ptr;
         P.pixels = (unsigned long long)c->width * c->height;
-        P.samplesPerBlock = c->samplesPerBlock;
-        const unsigned parts = (frameCount + c->samplesPerBlock - 1) / c->samplesPerBlock;
         P.tileCost = (unsigned int*)c->dTileCost.ptr;
-        P.tileOrder = nullptr;
+        P.blockList = nullptr;
+        P.blockCount = nullptr;
+        size_t gridBlocks = tiles;
         if (c->tileCostValid && c->tileOrdering) {
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(c->dTileSortTemp.ptr, c->tileSortBytes, (const uint32_t*)c->dTileCost.ptr,
-                                                                 (uint32_t*)c->dTileCostSorted.ptr, (const uint32_t*)c->dTileIds.ptr,
+            // at least four samples per block, at most 255 blocks per tile
+            const unsigned maxParts = split == 0 ? 1u : std::max(1u, std::min(255u, frameCount / 4u));
+            const unsigned tb = 256, tg = (unsigned)((tiles + tb - 1) / tb);
+            hipLaunchKernelGGL(planPartsKernel, dim3(1), dim3(1024), 0, c->stream, (const unsigned*)c->dTileCost.ptr, (unsigned)tiles,
+                               c->waveSlots, std::max(1u, split), maxParts, (unsigned*)c->dTileParts.ptr,
+                               (unsigned*)c->dTileKey.ptr);
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(c->dTileSortTemp.ptr, c->tileSortBytes, (const uint32_t*)c->dTileKey.ptr,
+                                                                 (uint32_t*)c->dTileKeySorted.ptr, (const uint32_t*)c->dTileIds.ptr,
                                                                  (uint32_t*)c->dTileOrder.ptr, (int)tiles, 0, 32, c->stream));
-            P.tileOrder = (const unsigned int*)c->dTileOrder.ptr;
+            hipLaunchKernelGGL(gatherPartsKernel, dim3(tg), dim3(tb), 0, c->stream, (const unsigned*)c->dTileOrder.ptr,
+                               (const unsigned*)c->dTileParts.ptr, (unsigned)tiles, (unsigned*)c->dPartsInOrder.ptr);
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->dScanTemp.ptr, c->scanBytes, (const uint32_t*)c->dPartsInOrder.ptr,
+                                                     (uint32_t*)c->dBlockStart.ptr, (int)tiles, c->stream));
+            hipLaunchKernelGGL(fillBlocksKernel, dim3(tg), dim3(tb), 0, c->stream, (const unsigned*)c->dTileOrder.ptr,
+                               (const unsigned*)c->dPartsInOrder.ptr, (const unsigned*)c->dBlockStart.ptr, (unsigned)tiles,
+                               (unsigned)capacity, frameCount, (unsigned*)c->dBlockList.ptr, (unsigned*)c->dBlockCount.ptr);
+            HIP_TRY(hipGetLastError());
+            P.blockList = (const unsigned int*)c->dBlockList.ptr;
+            P.blockCount = (const unsigned int*)c->dBlockCount.ptr;
+            gridBlocks = split == 0 ? tiles : capacity;  // blocks past the list's end find an empty sample range
         }
         HIP_TRY(hipMemsetAsync(c->dTileCost.ptr, 0, tiles * 4, c->stream));  // blocks add their lifetimes
         c->tileCostValid = true;
-        const dim3 grid((unsigned)(tiles * parts)), block(kMegaThreads);
+        if (counted) {
+            c->waveTimeCount = gridBlocks;
+            HIP_TRY(c->dWaveTimes.ensure(c->waveTimeCount * 16));
+            HIP_TRY(hipMemsetAsync(c->dWaveTimes.ptr, 0, c->waveTimeCount * 16, c->stream));
+            P.waveTimes = (unsigned long long*)c->dWaveTimes.ptr;
+        }
+        const dim3 grid((unsigned)gridBlocks), block(kMegaThreads);
         HIP_TRY(hipEventRecord(c->evTrace0, c->stream));
         // Trees up to 32 levels deep keep the whole traversal stack in LDS (8 KB per wave).  Deeper
         // ones keep 32 entries there and the rest in private memory, or (deepStackInLds, for A/B) get
@@ -489,7 +522,7 @@ int dispatchSplit(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t 
     // The megakernel writes one 48-byte record per (sample, pixel) and a resolve pass folds them into
     // the images; a launch takes as many frames as the sample buffer's budget holds.
     const uint64_t perFrame = (uint64_t)c->width * c->height * 48u;
-    uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(frameCount, c->sampleBudgetBytes / perFrame));
+    uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint32_t>(frameCount, 65535u), c->sampleBudgetBytes / perFrame));
     uint32_t done = 0;
     while (done < frameCount) {
         uint32_t n = std::min(chunk, frameCount - done);
@@ -529,6 +562,7 @@ int pt_create(int device, int width, int height, pt_ctx** out)
     c->device = device;
     c->width = width;
     c->height = height;
+    c->waveSlots = (uint32_t)std::max(1, prop.multiProcessorCount) * 4u * PT_WAVES_PER_SIMD;
     HIP_TRY(hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking));
     c->stream = c->ownStream;
     HIP_TRY(hipEventCreate(&c->evStart));
@@ -553,7 +587,8 @@ void pt_destroy(pt_ctx* c)
     if (!c) return;
     DeviceGuard guard(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DeviceBuffer* all[] = {&c->dSamples, &c->dTileCost, &c->dTileCostSorted, &c->dTileIds, &c->dTileOrder, &c->dTileSortTemp, &c->dWaveTimes, &c->dRefNodes, &c->dRefPrims, &c->dRgbStaging, &c->dNodes, &c->dTriangles, &c->dShading, &c->dMaterials, &c->dTextures, &c->dTexels,
+    DeviceBuffer* all[] = {&c->dSamples, &c->dTileCost, &c->dTileParts, &c->dTileKey, &c->dTileKeySorted, &c->dTileIds, &c->dTileOrder, &c->dTileSortTemp,
+                           &c->dPartsInOrder, &c->dBlockStart, &c->dBlockList, &c->dBlockCount, &c->dScanTemp, &c->dWaveTimes, &c->dRefNodes, &c->dRefPrims, &c->dRgbStaging, &c->dNodes, &c->dTriangles, &c->dShading, &c->dMaterials, &c->dTextures, &c->dTexels,
                            &c->dSrgbLut, &c->dEnvColorPdf, &c->dEnvSample, &c->dImages[0], &c->dImages[1],
                            &c->dImages[2], &c->dCounters};
     for (DeviceBuffer* b : all) b->release();
@@ -1074,7 +1109,8 @@ int pt_scene_bytes(pt_ctx* c, uint64_t* nodeBytes, uint64_t* triangleBytes, uint
 // threshold in 64ths of the live lanes; 2: wavefront refill threshold (idle lanes); 3: wavefront
 // iterations between read-backs of the live-ray count; 4: traverse grid size in blocks (0 = auto);
 // 5: megakernel hit-shading threshold in 64ths of the live lanes; 6: longest-tile-first launch order on/off;
-// 7: samples of a tile traced by one megakernel block; 8: sample-buffer budget in MiB (a dispatch is
+// 7: tile split: no megakernel block may cost more than 1/value of the launch's lower bound (0: one block per tile,
+// -1: chosen from the number of tiles per wave slot); 8: sample-buffer budget in MiB (a dispatch is
 // cut into launches whose sample records fit); 9: trees deeper than 32 levels keep their whole traversal
 // stack in LDS (1) instead of 32 entries there and the rest in private memory (0, the default).
 int pt_debug_set_tuning(pt_ctx* c, int key, int value)
@@ -1110,8 +1146,8 @@ int pt_debug_set_tuning(pt_ctx* c, int key, int value)
         c->tileOrdering = value != 0;
         return PT_OK;
     case 7:
-        if (value < 1 || value > 65536) return fail(PT_ERR_INVALID, "samples per block must be 1..65536");
-        c->samplesPerBlock = (uint32_t)value;
+        if (value < -1 || value > 64) return fail(PT_ERR_INVALID, "tile split must be -1..64");
+        c->tileSplit = value;
         return PT_OK;
     case 9:
         if (value != 0 && value != 1) return fail(PT_ERR_INVALID, "deep_stack_in_lds must be 0 or 1");

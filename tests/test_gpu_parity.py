@@ -222,16 +222,16 @@ def test_multi_frame_launch_equals_frame_by_frame(pipeline):
 
 def test_launch_splitting_does_not_change_a_bit():
     """The megakernel's sample buffer has a budget: a dispatch that exceeds it runs as several
-    launches.  A tile's samples can also be spread over several blocks.  Neither may change the
+    launches.  An expensive tile's samples are also spread over several blocks.  Neither may change the
     images, and the oracle's frame-by-frame running mean is the reference for all of them."""
     o, g = _pair("TorusMixed", 96, 80)
     p = R.default_params(96, 80)
     g.set_params(p)
     cpu = o.render(p, 96, 80, 3, 11, 2)  # FrameCount 3, 5, ..., 23
     frame_bytes_mib = 1  # 96*80*48 B = 0.35 MiB per frame: a 1 MiB budget holds 2 frames per launch
-    for tuning in (dict(), dict(sample_budget_mib=frame_bytes_mib), dict(samples_per_block=4),
-                   dict(sample_budget_mib=frame_bytes_mib, samples_per_block=1), dict(tile_order=0)):
-        g.set_tuning(**dict(dict(sample_budget_mib=8192, samples_per_block=65536, tile_order=1), **tuning))
+    for tuning in (dict(), dict(sample_budget_mib=frame_bytes_mib), dict(tile_split=16),
+                   dict(sample_budget_mib=frame_bytes_mib, tile_split=0), dict(tile_order=0)):
+        g.set_tuning(**dict(dict(sample_budget_mib=8192, tile_split=-1, tile_order=1), **tuning))
         g.clear()
         g.dispatch(3, 11, 2)
         for k in range(3):

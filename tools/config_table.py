@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Steady-state rates of the other benchmark configurations (bench.py times only the headline one):
+the reference's default scene at its default size, the headline scene at the reference's 3 bounces,
+a textured multi-material scene, and the many-material sphere field at 16 bounces.  One warm-up
+launch, then the median of three timed launches each; prints one line per configuration.
+
+    python tools/config_table.py [--spp 64]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pathtracer_amd import recipes, scenes  # noqa: E402
+from pathtracer_amd import renderer as R  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--spp", type=int, default=64)
+ap.add_argument("--tuning", default="", help="scheduler settings: key=value,key=value (Renderer.set_tuning)")
+args = ap.parse_args()
+
+hdri = scenes.sky_hdri(1024, 512)
+cache = R.calculate_hdri_cache(hdri)
+
+
+def run(name, width, height, bounces, meshes, mats, textures=(), eye=None, look_at=(0.0, 0.0, 0.0)):
+    g = R.Renderer(width, height)
+    for slot, texels, srgb in textures:
+        g.upload_texture(slot, texels, srgb)
+    for (v, i), m in zip(meshes, mats):
+        g.AddPathTracingModel(v, i, m)
+    g.ProcessBuffers()
+    g.upload_environment(hdri, cache)
+    p = R.default_params(width, height)
+    p.max_bounces = bounces
+    if eye is not None:
+        R.set_camera(p, eye, look_at, width, height)
+    g.set_params(p)
+    if args.tuning:
+        g.set_tuning(**{k: int(v) for k, v in (item.split("=") for item in args.tuning.split(","))})
+    g.clear()
+    g.dispatch(1, args.spp, 1)  # warm-up: also measures the tile costs the next launches are ordered by
+    g.synchronize()
+    ms, rays = [], 0
+    for _ in range(3):
+        g.clear()
+        g.dispatch(1, args.spp, 1, counted=False)
+        g.synchronize()
+        ms.append(g.last_dispatch_ms())
+        st = g.stats()
+        rays = st.rays_closest + st.rays_any
+    t = float(np.median(ms))
+    tris = sum(i.size // 3 for _, i in meshes)
+    print(f"{name:34s} {tris:8d} triangles {width}x{height} {bounces:2d} bounces {args.spp} spp: {t:8.2f} ms  "
+          f"{rays / t / 1e3:8.1f} Mrays/s  {args.spp / t * 1e3:8.1f} spp/s  {rays / (width * height * args.spp):.2f} rays/sample")
+
+
+m, a = scenes.flatten(scenes.recipe("BunnyClearcoat"))
+run("BunnyClearcoat (reference default)", 512, 512, 3, m, a)
+run("BunnyClearcoat", 1920, 1080, 3, m, a)
+m, a = scenes.flatten(scenes.recipe("DragonGlass"))
+v, i = scenes.subdivide(*m[0], 1)
+run("DragonGlass stand-in, 3 bounces", 1920, 1080, 3, [(v, i), m[1]], a)
+run("DragonGlass stand-in, 8 bounces", 1920, 1080, 8, [(v, i), m[1]], a)
+m, a, tex, _ = recipes.load_scene("Mill")
+run("Mill (3 textures)", 1920, 1080, 8, m, a, tex, eye=(14.0, 9.0, 16.0), look_at=(0.0, 5.0, 0.0))
+m, a, tex, _ = recipes.load_scene("AreaLight")
+run("AreaLight (emissive + transmissive)", 1920, 1080, 8, m, a, tex, eye=(0.5, 3.0, -8.0), look_at=(0.0, 1.2, 2.0))
+m, a = scenes.sphere_field()
+run("Sphere field, 65 materials", 1920, 1080, 16, m, a, eye=(-14.0, 7.0, 0.0))

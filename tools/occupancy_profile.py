@@ -41,6 +41,7 @@ print(f"  wave clock ticks: shading phases {pr[12]} ({pr[12] / max(pr[12] + pr[1
       f"per shading phase {pr[12] / pr[9]:.0f}, per traversal iteration {pr[13] / pr[0]:.0f}")
 print(f"  of the shading ticks: miss block {pr[15] / pr[12]:.1%}, hit block {pr[14] / pr[12]:.1%}, finish + new {1 - (pr[14] + pr[15]) / pr[12]:.1%}")
 wt, khz = g.wave_times()
+wt = wt[wt[:, 0] > 0]  # blocks past the end of the block list never start
 if len(wt):
     t0 = wt[:, 0].min()
     start, end = (wt[:, 0] - t0) / khz, (wt[:, 1] - t0) / khz  # ms
