@@ -439,8 +439,11 @@ __global__ void planPartsKernel(const unsigned* __restrict__ cost, unsigned tile
         __syncthreads();
     }
     const unsigned long long total = s_sum[0];
-    // largest cost a block may have: total / (slots * splitN), at least one tick
-    unsigned long long cap = total / ((unsigned long long)slots * splitN);
+    // largest cost a block may have: total / (slots * splitN), rounded up so that the extra blocks
+    // (sum of ceil(c / cap) - 1 < total / cap) can never outnumber slots * splitN, the room the
+    // block list has for them
+    const unsigned long long share = (unsigned long long)slots * splitN;
+    unsigned long long cap = (total + share - 1) / share;
     if (cap == 0) cap = 1;
     for (unsigned t = threadIdx.x; t < tiles; t += blockDim.x) {
         const unsigned long long c = cost[t];
