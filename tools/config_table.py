@@ -53,8 +53,15 @@ def run(name, width, height, bounces, meshes, mats, textures=(), eye=None, look_
         rays = st.rays_closest + st.rays_any
     t = float(np.median(ms))
     tris = sum(i.size // 3 for _, i in meshes)
+    # wave utilisation from the counting build of the same launch
+    g.clear()
+    g.dispatch(1, args.spp, 1, counted=True)
+    g.synchronize()
+    st, pr = g.stats(), g.profile()
     print(f"{name:34s} {tris:8d} triangles {width}x{height} {bounces:2d} bounces {args.spp} spp: {t:8.2f} ms  "
-          f"{rays / t / 1e3:8.1f} Mrays/s  {args.spp / t * 1e3:8.1f} spp/s  {rays / (width * height * args.spp):.2f} rays/sample")
+          f"{rays / t / 1e3:8.1f} Mrays/s  {args.spp / t * 1e3:8.1f} spp/s  {rays / (width * height * args.spp):.2f} rays/sample  "
+          f"{st.node_visits / rays:5.1f} visits + {st.triangle_tests / rays:4.1f} tests per ray  "
+          f"lanes per traversal iteration {pr[1] / max(pr[0], 1):4.1f}, per hit block {pr[7] / max(pr[6], 1):4.1f}")
 
 
 m, a = scenes.flatten(scenes.recipe("BunnyClearcoat"))
