@@ -307,7 +307,8 @@ int pt_debug_set_tuning(pt_ctx* ctx, int key, int value);
 int pt_debug_get_profile(pt_ctx* ctx, uint64_t out16[16]);
 /* Profiling hook (no counterpart in the reference): device wall-clock ticks at the start and end of every
  * wave of the most recent pt_dispatch_counted() under the megakernel scheduler, as (start, end) pairs
- * in tile order; *clock_khz_out = tick rate.  NULL pairs_out queries the count. */
+ * per block of the grid (start = 0: the block found no work); *clock_khz_out = tick rate.  NULL pairs_out
+ * queries the count. */
 int pt_debug_get_wave_times(pt_ctx* ctx, uint64_t* pairs_out, size_t capacity, size_t* count_out, int* clock_khz_out);
 
 /* Test hook, not part of the drop-in surface (no counterpart in the reference): evaluates one

@@ -2,17 +2,20 @@
 //
 // Two schedulers drive the same per-ray and per-hit device code (same bits out of both):
 //
-//  * MEGAKERNEL (default): a persistent per-wave state machine in ONE launch.  One lane owns one
-//    pixel and walks its samples in order; a wave covers an 8x8 pixel tile.  Every lane is in one
-//    of four modes -- NEW (start the next sample), SHADE (a closest-hit query finished), TRAV (a
-//    BVH query is in flight), FINISH (accumulate the sample) -- and the wave alternates between
+//  * MEGAKERNEL (default): a persistent per-wave state machine in ONE launch.  A wave covers an
+//    8x8 pixel tile and owns the tile's (pixel, sample) pairs of the launch as a pool; a lane that
+//    needs work takes the next pair.  Every lane is in one of four modes -- NEW (take a sample),
+//    SHADE (a closest-hit query finished), TRAV (a BVH query is in flight), FINISH (write the
+//    sample out) -- and the wave alternates between
 //      - a traversal phase, in which all TRAV lanes advance their query one step per iteration
 //        (closest-hit and shadow queries side by side) until the share of lanes still traversing
 //        falls below a threshold, and
-//      - a shading phase, in which the lanes whose query finished shade their hit or accumulate
-//        their sample and regenerate a primary ray, and re-enter the traversal phase next to the
-//        lanes whose query is still under way (their stack and cursor persist).
-//    Path state never leaves the registers.
+//      - a shading phase, in which the lanes whose query finished shade their miss or (once enough
+//        of them wait) their hit, write finished samples to the sample buffer, generate primary
+//        rays for new ones, and re-enter the traversal phase next to the lanes whose query is still
+//        under way (their stack and cursor persist).
+//    Path state never leaves the registers.  resolveKernel then folds the sample buffer into the
+//    images in FrameCount order.
 //  * WAVEFRONT pipeline (kept for A/B measurements): path state in global memory (one slot per
 //    pixel); per iteration a persistent traverseKernel pulls tagged ray entries from a queue
 //    (ballot-and-prefix hand-out from per-wave chunks) and a shadeKernel shades one hit per lane
@@ -21,8 +24,9 @@
 //    iterations of two launches for 16 samples) it measured 2.7x slower than the megakernel.
 //
 // Common rules
-//   * One pixel's FrameCount values (samples) are traced strictly one after the other, so the
-//     images are accumulated in frame order exactly like frame-by-frame dispatches.
+//   * A pixel's samples enter its running mean in FrameCount order (the megakernel's resolve pass
+//     and the wavefront pipeline's sample-after-sample walk both see to it), so the images carry the
+//     bits of frame-by-frame dispatches.
 //   * One shading pass emits both rays of a bounce.  The shader traces the shadow ray in the
 //     middle of its bounce; everything it computes after an unoccluded shadow ray (light
 //     radiance, BSDF value, MIS weight) does not depend on the ray's outcome, so it is
@@ -43,10 +47,10 @@
 namespace ptcore {
 
 constexpr int kBlockThreads = 256;
-// Waves per SIMD the megakernel is compiled for.  Measured on the benchmark scene with every wave
-// slot kept busy (longest-tile-first launch order): 4 waves (128 VGPRs, ~110 spilled values, all
-// outside the traversal loop) 54.4 ms per 64-spp launch, 3 waves (168 VGPRs, 25 spills) 56.5 ms,
-// 2 waves 73.6 ms, 5 waves (96 VGPRs, ~185 spills) 99 ms.
+// Waves per SIMD the megakernel is compiled for.  Measured on the benchmark scene (cache resident,
+// VALU bound): 4 waves (128 VGPRs, ~105 spilled values, all outside the traversal loop) and 3 waves
+// (168 VGPRs, 25 spills) within 0.5 % of each other, 2 waves 35 % slower, 5 waves (96 VGPRs, ~185
+// spills) 80 % slower.  Scenes that miss the caches want the occupancy: 4.
 #ifndef PT_WAVES_PER_SIMD
 #define PT_WAVES_PER_SIMD 4
 #endif
@@ -689,7 +693,7 @@ __global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(
             atomicAdd(&counters->triangleTests, (unsigned long long)sTris);
             atomicMax(&counters->maxStack, m);
             for (int i = 0; i < 16; i++) atomicAdd(&counters->profile[i], prof[i]);
-            if (P.waveTimes) {
+            if (P.waveTimes && kCount) {
                 P.waveTimes[2 * (size_t)blockIdx.x] = waveStart;
                 P.waveTimes[2 * (size_t)blockIdx.x + 1] = wall_clock64();
             }

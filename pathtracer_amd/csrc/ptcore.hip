@@ -513,7 +513,7 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
 }
 
 // A launch of many frames with no tile costs on record yet (first launch, new image size, new
-// geometry) is split: a short probe launch measures the costs, the rest runs longest tile first.
+// geometry) is split: a short probe launch measures the costs, the rest runs from the plan made of them.
 // Frame order per pixel is unchanged, so are the results.
 int dispatchSplit(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t frameStride, bool counted)
 {
@@ -1108,7 +1108,7 @@ int pt_scene_bytes(pt_ctx* c, uint64_t* nodeBytes, uint64_t* triangleBytes, uint
 // Tuning hook.  key 0: pipeline (0 megakernel, 1 wavefront); 1: megakernel traversal-phase exit
 // threshold in 64ths of the live lanes; 2: wavefront refill threshold (idle lanes); 3: wavefront
 // iterations between read-backs of the live-ray count; 4: traverse grid size in blocks (0 = auto);
-// 5: megakernel hit-shading threshold in 64ths of the live lanes; 6: longest-tile-first launch order on/off;
+// 5: megakernel hit-shading threshold in 64ths of the live lanes; 6: launch plan from the previous launch's tile costs on/off;
 // 7: tile split: no megakernel block may cost more than 1/value of the launch's lower bound (0: one block per tile,
 // -1: chosen from the number of tiles per wave slot); 8: sample-buffer budget in MiB (a dispatch is
 // cut into launches whose sample records fit); 9: trees deeper than 32 levels keep their whole traversal
@@ -1162,7 +1162,8 @@ int pt_debug_set_tuning(pt_ctx* c, int key, int value)
 }
 
 // Profiling hook: wall-clock ticks at the start and the end of every wave of the most recent
-// pt_dispatch_counted() with the megakernel scheduler, in tile order (pairs: start, end).
+// pt_dispatch_counted() with the megakernel scheduler, one pair (start, end) per block of the grid; blocks
+// that found no work have start = 0.
 int pt_debug_get_wave_times(pt_ctx* c, uint64_t* pairsOut, size_t capacity, size_t* countOut, int* clockKhzOut)
 {
     if (!c || !countOut) return fail(PT_ERR_INVALID, "null argument");

@@ -138,7 +138,8 @@ class Renderer:
         return list(out)
 
     def wave_times(self):
-        """-> ((n, 2) uint64 start/end ticks per wave in tile order, tick rate in kHz) of the last counted dispatch."""
+        """-> ((n, 2) uint64 start/end ticks per block of the grid (start 0: the block found no work), tick rate
+        in kHz) of the last counted dispatch."""
         n, khz = ctypes.c_size_t(), ctypes.c_int()
         check(self._lib.pt_debug_get_wave_times(self._h, None, 0, ctypes.byref(n), ctypes.byref(khz)))
         out = np.zeros((n.value, 2), np.uint64)
