@@ -238,6 +238,29 @@ def test_launch_splitting_does_not_change_a_bit():
             assert g.read_image(k).tobytes() == cpu[k].tobytes(), (tuning, k)
 
 
+def test_uhd_launch_equals_frame_by_frame_and_oracle_bands():
+    """3840 x 2160 (the largest benchmark configuration's frame): one 6-frame dispatch equals six
+    one-frame dispatches bit for bit, and bands of rows equal the oracle."""
+    o, g = _pair("BunnyClearcoat", 3840, 2160)
+    p = R.default_params(3840, 2160)
+    g.set_params(p)
+    g.clear()
+    g.dispatch(1, 6, 1)
+    whole = [g.read_image(k) for k in range(3)]
+    g.clear()
+    for f in range(1, 7):
+        g.dispatch(f, 1, 1)
+    for k in range(3):
+        assert g.read_image(k).tobytes() == whole[k].tobytes()
+    g.clear()
+    g.dispatch(1, 2, 1)
+    gpu = [g.read_image(k) for k in range(3)]
+    for y0, y1 in ((0, 4), (1078, 1082), (2156, 2160)):
+        cpu = o.render(p, 3840, 2160, 1, 2, 1, rows=(y0, y1))
+        for k in range(3):
+            assert gpu[k][y0:y1].tobytes() == cpu[k][y0:y1].tobytes(), (y0, k)
+
+
 def test_full_hd_launch_properties():
     """At the benchmark's image size the oracle is too slow to render every pixel, so the full-size
     launch is checked through properties: one 12-frame dispatch equals 12 one-frame dispatches bit for
