@@ -60,7 +60,7 @@ def build_workload(args):
         work.update(nodes=None, prims=R.align_primitives(prims), bvh_seconds=None)
     else:
         t0 = time.time()
-        prims_sorted, nodes40 = R.build_bvh_sah(prims, 4)
+        prims_sorted, nodes40 = R.build_bvh_sah(prims, 4, full_sweep=getattr(args, "bvh", "host") == "full-sweep")
         work.update(nodes=R.align_nodes(nodes40), prims=R.align_primitives(prims_sorted), bvh_seconds=time.time() - t0)
     return work
 
@@ -113,7 +113,7 @@ def main():
                     help="midpoint-subdivide the bunny this many times (default 1: 576 k triangles; 0 with --copies)")
     ap.add_argument("--copies", type=int, default=1,
                     help="instanced-scene stress: this many bunnies flattened on a jittered grid (139 = 20 M triangles)")
-    ap.add_argument("--bvh", choices=["host", "device"], default="host",
+    ap.add_argument("--bvh", choices=["host", "full-sweep", "device"], default="host",
                     help="host: the reference's sweep-SAH builder (bit-identical tree); device: GPU linear BVH")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tuning", default="", help="scheduler settings for A/B runs: key=value,key=value (Renderer.set_tuning)")
@@ -228,7 +228,8 @@ def main():
                               if args.copies == 1 else
                               f"DragonGlass recipe on {args.copies} flattened bunnies + floor ({work['triangles']} triangles), ") +
                              f"{W}x{H}, max {args.bounces} bounces, {S} spp per step per GPU, analytic sky HDRI 1024x512, "
-                             f"BVH built by the {'GPU linear-BVH builder' if args.bvh == 'device' else 'sweep-SAH host builder (the reference tree)'}"),
+                             "BVH built by the " + {"device": "GPU linear-BVH builder", "host": "sweep-SAH host builder (the reference tree)",
+                                                      "full-sweep": "sweep-SAH host builder without the reference's cost cap"}[args.bvh]),
                 "width": W, "height": H, "max_bounces": args.bounces, "spp_per_step_per_gpu": S,
                 "total_spp": total_spp, "parallelism": f"sample-sharded x{world}" if world > 1 else "single GPU",
                 "bvh_build_seconds": round(work["bvh_seconds"], 3),

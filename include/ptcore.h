@@ -177,6 +177,17 @@ int pt_align_primitives(const void* prims100, size_t count, void* prims112_out);
 /* CalculateHdriCache (PathTracingRenderer.cpp:803-901): cache_out = w*h*3 floats. */
 int pt_calculate_hdri_cache(const float* hdri_rgb, int width, int height, float* cache_out);
 
+/* The same sweep builder without the reference's cost cap (no counterpart in the reference).
+ * BVH.cpp accepts a split only while its cost, area x count, stays below the constant 114514
+ * (BVH.cpp:4,132-134,209-222); a node that exceeds it is cut at the median along X, which is what the
+ * top levels of every scene of more than a few thousand triangles get.  Here every node takes its
+ * best sweep split: a different, better tree (a third of the node visits per ray on the benchmark
+ * scene), same node and primitive layouts, images equal to the reference tree's except where
+ * distances tie exactly.  Arguments as pt_build_bvh_sah / pt_process_buffers. */
+int pt_build_bvh_full_sweep(void* prims100, size_t count, int leaf_size, void* nodes40_out, size_t node_capacity,
+                            size_t* node_count_out);
+int pt_process_buffers_full_sweep(pt_ctx* ctx);
+
 /* BVH construction on the GPU (no counterpart in the reference): a linear BVH over Morton-sorted
  * triangle centroids, leaves of at most 4 triangles, for scenes where BVH::BuildBvhWithSah's
  * O(n log^2 n) sweep takes minutes.  The tree differs from the one BVH.cpp builds (lower SAH quality),

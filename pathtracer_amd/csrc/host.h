@@ -10,8 +10,10 @@
 namespace ptcore {
 
 // host_bvh.cpp
+// uncapped = false: the reference's builder bit for bit.  uncapped = true: the same sweep without the
+// reference's cost cap (every node takes its best SAH split).
 size_t BuildBvhWithSah(RefPrimitive* prims, size_t count, int leafSize, std::vector<RefNode>& nodes,
-                       int threads = 0);
+                       int threads = 0, bool uncapped = false);
 void AssemblePrimitives(const RefVertex* v, const void* indices, size_t indexCount, int indexBytes,
                         uint32_t meshIndex, RefPrimitive* out);
 void AlignNodes(const RefNode* in, size_t count, RefNodeAlign* out);

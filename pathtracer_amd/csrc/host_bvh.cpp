@@ -30,7 +30,7 @@
 namespace ptcore {
 namespace {
 
-constexpr float kInf = 114514.0f;  // BVH.cpp:4 -- also the cost cap that triggers the median fallback
+constexpr float kRefInf = 114514.0f;  // BVH.cpp:4 -- also the cost cap that triggers the median fallback
 
 struct Key {
     float c[3];   // centroid, (A + B + C) / 3 per component (BVH.cpp:8)
@@ -51,6 +51,11 @@ struct Builder {
     int leafSize;
     int parallelCutoff;
     std::atomic<int>& threadsLeft;
+    // The reference's "infinity": the seed of its running bounds and, more importantly, the cost a
+    // split has to beat.  With 114514 (BVH.cpp:4) a node whose best area x count reaches that value
+    // keeps the default split, the median along X (BVH.cpp:132-134,209-222): that is what the top
+    // levels of every large scene get.  With FLT_MAX every node takes its best sweep split.
+    float kInf;
 
     // Builds the sub-tree over keys[l..r] into `out` with LOCAL pre-order ids (root = 0,
     // child ids relative to this vector).  `index` fields are absolute primitive positions.
@@ -193,7 +198,8 @@ struct Builder {
 // sub-tree is built in place (same vector as its parent) its "local" ids are already the
 // parent's ids, so only spliced sub-trees are shifted.  The top-level call builds into a
 // vector that already holds the dummy node 0, which makes the root id 1 like the reference.
-size_t BuildBvhWithSah(RefPrimitive* prims, size_t count, int leafSize, std::vector<RefNode>& nodes, int threads)
+size_t BuildBvhWithSah(RefPrimitive* prims, size_t count, int leafSize, std::vector<RefNode>& nodes, int threads,
+                       bool uncapped)
 {
     nodes.clear();
     nodes.push_back(RefNode{});  // zeroed dummy node 0 (PathTracingRenderer.cpp:575-576)
@@ -216,7 +222,7 @@ size_t BuildBvhWithSah(RefPrimitive* prims, size_t count, int leafSize, std::vec
         if (threads < 1) threads = 1;
     }
     std::atomic<int> threadsLeft(threads - 1);
-    Builder b{bounds, keys, leafSize, 4096, threadsLeft};
+    Builder b{bounds, keys, leafSize, 4096, threadsLeft, uncapped ? 3.402823466e38f : kRefInf};
     b.build(0, (int)count - 1, nodes);
 
     std::vector<RefPrimitive> sorted(count);

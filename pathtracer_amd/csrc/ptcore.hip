@@ -750,7 +750,14 @@ int pt_clear_models(pt_ctx* c)
     return PT_OK;
 }
 
-int pt_process_buffers(pt_ctx* c)
+namespace {
+int processBuffers(pt_ctx* c, bool uncapped);
+}
+int pt_process_buffers(pt_ctx* c) { return processBuffers(c, false); }
+int pt_process_buffers_full_sweep(pt_ctx* c) { return processBuffers(c, true); }
+
+namespace {
+int processBuffers(pt_ctx* c, bool uncapped)
 {
     if (!c) return fail(PT_ERR_INVALID, "null context");
     if (c->models.empty()) return fail(PT_ERR_STATE, "no models added");
@@ -768,7 +775,7 @@ int pt_process_buffers(pt_ctx* c)
         meshIndex++;
     }
     std::vector<RefNode> nodes;
-    BuildBvhWithSah(soup.data(), soup.size(), 4, nodes);
+    BuildBvhWithSah(soup.data(), soup.size(), 4, nodes, 0, uncapped);
     std::vector<RefNodeAlign> nodesAligned(nodes.size());
     std::vector<RefPrimitiveAlign> primsAligned(soup.size());
     AlignNodes(nodes.data(), nodes.size(), nodesAligned.data());
@@ -780,17 +787,28 @@ int pt_process_buffers(pt_ctx* c)
     return pt_upload_primitives(c, primsAligned.data(), primsAligned.size());
 }
 
-int pt_build_bvh_sah(void* prims100, size_t count, int leafSize, void* nodes40Out, size_t nodeCapacity, size_t* nodeCountOut)
+int buildBvhSah(void* prims100, size_t count, int leafSize, void* nodes40Out, size_t nodeCapacity, size_t* nodeCountOut,
+                bool uncapped)
 {
     if (!prims100 || !nodes40Out || !nodeCountOut) return fail(PT_ERR_INVALID, "null argument");
     if (leafSize < 1) return fail(PT_ERR_INVALID, "leaf_size must be >= 1");
     if (count > 0x7fffffffu) return fail(PT_ERR_INVALID, "too many primitives");
     std::vector<RefNode> nodes;
-    BuildBvhWithSah((RefPrimitive*)prims100, count, leafSize, nodes);
+    BuildBvhWithSah((RefPrimitive*)prims100, count, leafSize, nodes, 0, uncapped);
     if (nodes.size() > nodeCapacity) return fail(PT_ERR_INVALID, "node_capacity too small: need " + std::to_string(nodes.size()));
     std::memcpy(nodes40Out, nodes.data(), nodes.size() * sizeof(RefNode));
     *nodeCountOut = nodes.size();
     return PT_OK;
+}
+}  // namespace
+
+int pt_build_bvh_sah(void* prims100, size_t count, int leafSize, void* nodes40Out, size_t nodeCapacity, size_t* nodeCountOut)
+{
+    return buildBvhSah(prims100, count, leafSize, nodes40Out, nodeCapacity, nodeCountOut, false);
+}
+int pt_build_bvh_full_sweep(void* prims100, size_t count, int leafSize, void* nodes40Out, size_t nodeCapacity, size_t* nodeCountOut)
+{
+    return buildBvhSah(prims100, count, leafSize, nodes40Out, nodeCapacity, nodeCountOut, true);
 }
 
 int pt_assemble_primitives(const void* vertices32, size_t vertexCount, const void* indices, size_t indexCount,

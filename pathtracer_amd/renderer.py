@@ -92,8 +92,9 @@ class Renderer:
     def ClearPathTracingModels(self):
         check(self._lib.pt_clear_models(self._h))
 
-    def ProcessBuffers(self):
-        check(self._lib.pt_process_buffers(self._h))
+    def ProcessBuffers(self, full_sweep=False):
+        """full_sweep: the sweep-SAH builder without the reference's cost cap (a different, better tree)."""
+        check((self._lib.pt_process_buffers_full_sweep if full_sweep else self._lib.pt_process_buffers)(self._h))
 
     def ProcessBuffersDevice(self):
         """ProcessBuffers with the BVH built on the GPU (Morton-code linear BVH) instead of the sweep SAH."""
@@ -231,14 +232,16 @@ def set_camera(params, eye, center, width, height, fovy=1.57, up=(0.0, 1.0, 0.0)
     return params
 
 
-def build_bvh_sah(prims100, leaf_size=4):
-    """prims100: (n, 25) float32 view of 100-B records. Returns (reordered prims, nodes (m, 10))."""
+def build_bvh_sah(prims100, leaf_size=4, full_sweep=False):
+    """prims100: (n, 25) float32 view of 100-B records. Returns (reordered prims, nodes (m, 10)).
+    full_sweep: without the reference's cost cap (a different, better tree)."""
     p = np.ascontiguousarray(prims100, dtype=np.float32).copy()
     assert p.nbytes % 100 == 0
     n = p.nbytes // 100
     nodes = np.zeros((2 * n + 2, 10), np.float32)
     cnt = ctypes.c_size_t()
-    check(_l.load().pt_build_bvh_sah(_ptr(p), n, int(leaf_size), _ptr(nodes), nodes.shape[0], ctypes.byref(cnt)))
+    build = _l.load().pt_build_bvh_full_sweep if full_sweep else _l.load().pt_build_bvh_sah
+    check(build(_ptr(p), n, int(leaf_size), _ptr(nodes), nodes.shape[0], ctypes.byref(cnt)))
     return p, nodes[:cnt.value].copy()
 
 

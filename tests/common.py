@@ -34,3 +34,61 @@ def environment(width=256, height=128):
     hdri = scenes.sky_hdri(width, height)
     cache = R.calculate_hdri_cache(hdri)
     return hdri, cache
+
+
+def nodes_view(nodes48):
+    raw = np.ascontiguousarray(nodes48).view(np.int32).reshape(-1, 12)
+    f = np.ascontiguousarray(nodes48).view(np.float32).reshape(-1, 12)
+    return raw[:, 0], raw[:, 1], raw[:, 2], raw[:, 3], f[:, 4:7], f[:, 8:11]
+
+
+def check_tree(nodes48, prims112, source112):
+    """Every primitive in exactly one leaf, leaves of 1..4, boxes tight around their contents."""
+    left, right, n, index, lo, hi = nodes_view(nodes48)
+    p = np.ascontiguousarray(prims112).view(np.float32).reshape(-1, 28)
+    src = np.ascontiguousarray(source112).view(np.float32).reshape(-1, 28)
+    # same multiset of primitive records (compare as raw bytes)
+    a = np.sort(np.ascontiguousarray(p).view("V112").ravel())
+    b = np.sort(np.ascontiguousarray(src).view("V112").ravel())
+    assert a.tobytes() == b.tobytes()
+    pmin = np.minimum(np.minimum(p[:, 0:3], p[:, 8:11]), p[:, 16:19])
+    pmax = np.maximum(np.maximum(p[:, 0:3], p[:, 8:11]), p[:, 16:19])
+    covered = np.zeros(p.shape[0], np.int32)
+    seen = np.zeros(left.shape[0], np.int32)
+    stack, depth_max, interior = [(1, 1)], 0, 0
+    while stack:
+        k, depth = stack.pop()
+        seen[k] += 1
+        depth_max = max(depth_max, depth)
+        if n[k] > 0:
+            assert 1 <= n[k] <= 4
+            sl = slice(index[k], index[k] + n[k])
+            covered[sl] += 1
+            assert np.array_equal(lo[k], pmin[sl].min(0)) and np.array_equal(hi[k], pmax[sl].max(0))
+        else:
+            interior += 1
+            for c in (left[k], right[k]):
+                assert 1 < c < left.shape[0]
+                assert (lo[c] >= lo[k]).all() and (hi[c] <= hi[k]).all()
+                stack.append((c, depth + 1))
+            assert np.array_equal(lo[k], np.minimum(lo[left[k]], lo[right[k]]))
+            assert np.array_equal(hi[k], np.maximum(hi[left[k]], hi[right[k]]))
+    assert (covered == 1).all()
+    assert (seen[1:] == 1).all() and seen[0] == 0
+    return depth_max, interior
+
+
+def sah_cost(nodes48):
+    left, right, n, index, lo, hi = nodes_view(nodes48)
+    d = (hi - lo).astype(np.float64)
+    area = 2.0 * (d[:, 0] * d[:, 1] + d[:, 1] * d[:, 2] + d[:, 2] * d[:, 0])
+    used = np.zeros(left.shape[0], bool)
+    stack = [1]
+    while stack:
+        k = stack.pop()
+        used[k] = True
+        if n[k] == 0:
+            stack += [left[k], right[k]]
+    leaf = used & (n > 0)
+    inner = used & (n == 0)
+    return (area[inner].sum() * 1.0 + (area[leaf] * n[leaf]).sum() * 1.0) / area[1]

@@ -8,68 +8,10 @@ from oracle import binding as ob
 from pathtracer_amd import renderer as R
 from pathtracer_amd import scenes
 from pathtracer_amd.lib import PtError
-from tests.common import environment, soup
+from tests.common import check_tree as _check_tree, environment, sah_cost as _sah_cost, soup
 from tests.test_gpu_parity import _assert_images_equal
 
 pytestmark = pytest.mark.gpu
-
-
-def _nodes_view(nodes48):
-    raw = np.ascontiguousarray(nodes48).view(np.int32).reshape(-1, 12)
-    f = np.ascontiguousarray(nodes48).view(np.float32).reshape(-1, 12)
-    return raw[:, 0], raw[:, 1], raw[:, 2], raw[:, 3], f[:, 4:7], f[:, 8:11]
-
-
-def _check_tree(nodes48, prims112, source112):
-    """Every primitive in exactly one leaf, leaves of 1..4, boxes tight around their contents."""
-    left, right, n, index, lo, hi = _nodes_view(nodes48)
-    p = np.ascontiguousarray(prims112).view(np.float32).reshape(-1, 28)
-    src = np.ascontiguousarray(source112).view(np.float32).reshape(-1, 28)
-    # same multiset of primitive records (compare as raw bytes)
-    a = np.sort(np.ascontiguousarray(p).view("V112").ravel())
-    b = np.sort(np.ascontiguousarray(src).view("V112").ravel())
-    assert a.tobytes() == b.tobytes()
-    pmin = np.minimum(np.minimum(p[:, 0:3], p[:, 8:11]), p[:, 16:19])
-    pmax = np.maximum(np.maximum(p[:, 0:3], p[:, 8:11]), p[:, 16:19])
-    covered = np.zeros(p.shape[0], np.int32)
-    seen = np.zeros(left.shape[0], np.int32)
-    stack, depth_max, interior = [(1, 1)], 0, 0
-    while stack:
-        k, depth = stack.pop()
-        seen[k] += 1
-        depth_max = max(depth_max, depth)
-        if n[k] > 0:
-            assert 1 <= n[k] <= 4
-            sl = slice(index[k], index[k] + n[k])
-            covered[sl] += 1
-            assert np.array_equal(lo[k], pmin[sl].min(0)) and np.array_equal(hi[k], pmax[sl].max(0))
-        else:
-            interior += 1
-            for c in (left[k], right[k]):
-                assert 1 < c < left.shape[0]
-                assert (lo[c] >= lo[k]).all() and (hi[c] <= hi[k]).all()
-                stack.append((c, depth + 1))
-            assert np.array_equal(lo[k], np.minimum(lo[left[k]], lo[right[k]]))
-            assert np.array_equal(hi[k], np.maximum(hi[left[k]], hi[right[k]]))
-    assert (covered == 1).all()
-    assert (seen[1:] == 1).all() and seen[0] == 0
-    return depth_max, interior
-
-
-def _sah_cost(nodes48):
-    left, right, n, index, lo, hi = _nodes_view(nodes48)
-    d = (hi - lo).astype(np.float64)
-    area = 2.0 * (d[:, 0] * d[:, 1] + d[:, 1] * d[:, 2] + d[:, 2] * d[:, 0])
-    used = np.zeros(left.shape[0], bool)
-    stack = [1]
-    while stack:
-        k = stack.pop()
-        used[k] = True
-        if n[k] == 0:
-            stack += [left[k], right[k]]
-    leaf = used & (n > 0)
-    inner = used & (n == 0)
-    return (area[inner].sum() * 1.0 + (area[leaf] * n[leaf]).sum() * 1.0) / area[1]
 
 
 def _render_pair(nodes, prims, mats, width, height, bounces, device_built):
@@ -154,3 +96,24 @@ def test_process_buffers_device_and_errors():
     with pytest.raises(PtError, match="meshIndex") as e:
         g.dispatch(2, 1, 1)
     assert e.value.code == -5
+
+
+def test_full_sweep_tree_renders_like_the_oracle_and_like_the_reference_tree():
+    """The sweep builder without the reference's cost cap gives another tree over the same triangles:
+    the GPU image equals the oracle's on that tree bit for bit, and equals the image traced through
+    the reference's tree (the closest hit does not depend on the tree unless distances tie exactly)."""
+    prims100, mats = soup(scenes.recipe("BunnyGlass"))
+    width, height = 160, 128
+    images = {}
+    for full in (False, True):
+        sorted_prims, nodes40 = R.build_bvh_sah(prims100, 4, full_sweep=full)
+        nodes, prims = R.align_nodes(nodes40), R.align_primitives(sorted_prims)
+        g = R.Renderer(width, height)
+        g.upload_nodes(nodes)
+        g.upload_primitives(prims)
+        gpu, cpu = _render_pair(nodes, prims, mats, width, height, 8, g)
+        _assert_images_equal(gpu, cpu[:3], cpu[3], f"BunnyGlass, full_sweep={full}")
+        images[full] = gpu
+    for a, b in zip(images[False], images[True]):
+        differing = int(np.any(a.view(np.uint32) != b.view(np.uint32), axis=-1).sum())
+        assert differing <= 1e-4 * width * height, differing

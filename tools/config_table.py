@@ -18,6 +18,8 @@ from pathtracer_amd import renderer as R  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--spp", type=int, default=64)
+ap.add_argument("--bvh", choices=["host", "full-sweep", "device"], default="host",
+                help="host: the reference's builder; full-sweep: the same without its cost cap; device: GPU linear BVH")
 ap.add_argument("--tuning", default="", help="scheduler settings: key=value,key=value (Renderer.set_tuning)")
 args = ap.parse_args()
 
@@ -31,7 +33,10 @@ def run(name, width, height, bounces, meshes, mats, textures=(), eye=None, look_
         g.upload_texture(slot, texels, srgb)
     for (v, i), m in zip(meshes, mats):
         g.AddPathTracingModel(v, i, m)
-    g.ProcessBuffers()
+    if args.bvh == "device":
+        g.ProcessBuffersDevice()
+    else:
+        g.ProcessBuffers(full_sweep=args.bvh == "full-sweep")
     g.upload_environment(hdri, cache)
     p = R.default_params(width, height)
     p.max_bounces = bounces
