@@ -18,6 +18,7 @@
 #include "host.h"
 #include "kernels.h"
 #include "lbvh.h"
+#include "ploc.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -116,6 +117,7 @@ struct pt_ctx {
     // finished samples of one launch, 48 B per (sample, pixel); resolved into the images after the launch
     DeviceBuffer dSamples;
     uint64_t sampleBudgetBytes = 8ull << 30;
+    int plocRadius = 16;  // device BVH builder: neighbours searched on either side per clustering round (0: Morton radix tree)
     bool deepStackInLds = false;  // trees deeper than 32 levels: whole stack in LDS (12/16 KB per wave)
     size_t waveTimeCount = 0;
     // geometry built on the device (pt_build_bvh_device): the tree in the reference's layouts, kept for
@@ -1130,7 +1132,8 @@ int pt_scene_bytes(pt_ctx* c, uint64_t* nodeBytes, uint64_t* triangleBytes, uint
 // 7: tile split: no megakernel block may cost more than 1/value of the launch's lower bound (0: one block per tile,
 // -1: chosen from the number of tiles per wave slot); 8: sample-buffer budget in MiB (a dispatch is
 // cut into launches whose sample records fit); 9: trees deeper than 32 levels keep their whole traversal
-// stack in LDS (1) instead of 32 entries there and the rest in private memory (0, the default).
+// stack in LDS (1) instead of 32 entries there and the rest in private memory (0, the default); 10: device BVH
+// builder: clustering search radius (0 = Morton radix tree).
 int pt_debug_set_tuning(pt_ctx* c, int key, int value)
 {
     if (!c) return fail(PT_ERR_INVALID, "null context");
@@ -1170,6 +1173,10 @@ int pt_debug_set_tuning(pt_ctx* c, int key, int value)
     case 9:
         if (value != 0 && value != 1) return fail(PT_ERR_INVALID, "deep_stack_in_lds must be 0 or 1");
         c->deepStackInLds = value != 0;
+        return PT_OK;
+    case 10:
+        if (value < 0 || value > 256) return fail(PT_ERR_INVALID, "clustering radius must be 0..256");
+        c->plocRadius = value;
         return PT_OK;
     case 8:
         if (value < 1) return fail(PT_ERR_INVALID, "sample budget must be >= 1 MiB");
@@ -1249,13 +1256,88 @@ namespace {
 struct LbvhScratch {
     DeviceBuffer in, keys, keysSorted, values, order, sortTemp, parent, left, right, first, last, box, height, visits, emit,
         kept, emitAt, keptAt, scanTemp, bounds;
+    // clustering builder (ploc.h)
+    DeviceBuffer pLeft, pRight, pSize, pHeight, pBox, pPosition, idA, idB, boxA, boxB, nearest, flags, scan, finalOrder;
     ~LbvhScratch()
     {
         DeviceBuffer* all[] = {&in, &keys, &keysSorted, &values, &order, &sortTemp, &parent, &left, &right, &first, &last,
-                               &box, &height, &visits, &emit, &kept, &emitAt, &keptAt, &scanTemp, &bounds};
+                               &box, &height, &visits, &emit, &kept, &emitAt, &keptAt, &scanTemp, &bounds,
+                               &pLeft, &pRight, &pSize, &pHeight, &pBox, &pPosition, &idA, &idB, &boxA, &boxB, &nearest,
+                               &flags, &scan, &finalOrder};
         for (DeviceBuffer* b : all) b->release();
     }
 };
+
+// Tree topology by locally-ordered clustering over the Morton-sorted triangles (ploc.h), written
+// into the arrays the emit stage reads.  One small read-back per round (the cluster count).
+int buildPlocTopology(pt_ctx* c, LbvhScratch& w, const RefPrimitiveAlign* dIn, int n, LbvhTree T)
+{
+    const size_t count = (size_t)n, internal = count - 1;
+    HIP_TRY(w.pLeft.ensure(internal * 4));
+    HIP_TRY(w.pRight.ensure(internal * 4));
+    HIP_TRY(w.pSize.ensure(2 * count * 4));
+    HIP_TRY(w.pHeight.ensure(internal * 4));
+    HIP_TRY(w.pBox.ensure(2 * count * 24));
+    HIP_TRY(w.pPosition.ensure(2 * count * 4));
+    HIP_TRY(w.idA.ensure(count * 4));
+    HIP_TRY(w.idB.ensure(count * 4));
+    HIP_TRY(w.boxA.ensure(count * 24));
+    HIP_TRY(w.boxB.ensure(count * 24));
+    HIP_TRY(w.nearest.ensure(count * 4));
+    HIP_TRY(w.flags.ensure(count * 8));
+    HIP_TRY(w.scan.ensure(count * 8));
+    HIP_TRY(w.finalOrder.ensure(count * 4));
+    hipStream_t st = c->stream;
+    const dim3 block(256);
+    auto grid = [](size_t items) { return dim3((unsigned int)((items + 255) / 256)); };
+    PlocNodes N{(int*)w.pLeft.ptr, (int*)w.pRight.ptr, (int*)w.pSize.ptr, (int*)w.pHeight.ptr, (float*)w.pBox.ptr, (int*)w.pPosition.ptr};
+    int* idIn = (int*)w.idA.ptr;
+    int* idOut = (int*)w.idB.ptr;
+    float* boxIn = (float*)w.boxA.ptr;
+    float* boxOut = (float*)w.boxB.ptr;
+    hipLaunchKernelGGL(plocInitKernel, grid(count), block, 0, st, dIn, (const unsigned int*)w.order.ptr, n, idIn, boxIn, N);
+    HIP_TRY(hipGetLastError());
+    size_t scanBytes = 0;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes, (const unsigned long long*)w.flags.ptr,
+                                             (unsigned long long*)w.scan.ptr, n, st));
+    HIP_TRY(w.scanTemp.ensure(scanBytes));
+    std::vector<std::pair<int, int>> rounds;  // (first node created, nodes created) per round
+    int clusters = n, created = 0;
+    while (clusters > 1) {
+        hipLaunchKernelGGL(plocNearestKernel, grid((size_t)clusters), block, 0, st, (const float*)boxIn, clusters, c->plocRadius,
+                           (int*)w.nearest.ptr);
+        hipLaunchKernelGGL(plocFlagKernel, grid((size_t)clusters), block, 0, st, (const int*)w.nearest.ptr, clusters,
+                           (unsigned long long*)w.flags.ptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(w.scanTemp.ptr, scanBytes, (const unsigned long long*)w.flags.ptr,
+                                                 (unsigned long long*)w.scan.ptr, clusters, st));
+        hipLaunchKernelGGL(plocMergeKernel, grid((size_t)clusters), block, 0, st, (const int*)idIn, (const float*)boxIn,
+                           (const int*)w.nearest.ptr, (const unsigned long long*)w.flags.ptr,
+                           (const unsigned long long*)w.scan.ptr, clusters, created, n, idOut, boxOut, N);
+        HIP_TRY(hipGetLastError());
+        unsigned long long lastScan = 0, lastFlag = 0;
+        HIP_TRY(hipMemcpyAsync(&lastScan, (unsigned long long*)w.scan.ptr + (clusters - 1), 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&lastFlag, (unsigned long long*)w.flags.ptr + (clusters - 1), 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const unsigned long long total = lastScan + lastFlag;
+        const int survivors = (int)(unsigned int)total, merges = (int)(total >> 32);
+        if (merges < 1 || survivors != clusters - merges)
+            return fail(PT_ERR_DEVICE, "clustering builder made no progress (internal error)");
+        rounds.push_back({created, merges});
+        created += merges;
+        clusters = survivors;
+        std::swap(idIn, idOut);
+        std::swap(boxIn, boxOut);
+    }
+    if (created != n - 1) return fail(PT_ERR_DEVICE, "clustering builder lost nodes (internal error)");
+    HIP_TRY(hipMemsetAsync((int*)w.pPosition.ptr + (n + n - 2), 0, 4, st));  // the root's triangles start at 0
+    for (size_t r = rounds.size(); r-- > 0;)
+        hipLaunchKernelGGL(plocPositionKernel, grid((size_t)rounds[r].second), block, 0, st, rounds[r].first, rounds[r].second, n, N);
+    hipLaunchKernelGGL(plocRelabelKernel, grid(count), block, 0, st, n, N, (const unsigned int*)w.order.ptr,
+                       (unsigned int*)w.finalOrder.ptr, T);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
 
 int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count)
 {
@@ -1310,9 +1392,16 @@ int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count)
                (int*)w.last.ptr,   (float*)w.box.ptr,  (int*)w.height.ptr, (unsigned int*)w.visits.ptr};
     HIP_TRY(hipMemsetAsync(w.visits.ptr, 0, internal * 4, st));
     HIP_TRY(hipMemsetAsync(w.height.ptr, 0, internal * 4, st));
-    if (n > 1) hipLaunchKernelGGL(lbvhTreeKernel, gridNodes, block, 0, st, (const unsigned long long*)w.keysSorted.ptr, n, T);
-    hipLaunchKernelGGL(lbvhFitKernel, gridPrims, block, 0, st, dIn, (const unsigned int*)w.order.ptr, n, T);
-    hipLaunchKernelGGL(lbvhEmitTrianglesKernel, gridPrims, block, 0, st, dIn, (const unsigned int*)w.order.ptr, un,
+    const unsigned int* finalOrder = (const unsigned int*)w.order.ptr;
+    if (c->plocRadius > 0 && n > kLbvhLeafMax) {
+        int rc = buildPlocTopology(c, w, dIn, n, T);
+        if (rc != PT_OK) return rc;
+        finalOrder = (const unsigned int*)w.finalOrder.ptr;
+    } else {
+        if (n > 1) hipLaunchKernelGGL(lbvhTreeKernel, gridNodes, block, 0, st, (const unsigned long long*)w.keysSorted.ptr, n, T);
+        hipLaunchKernelGGL(lbvhFitKernel, gridPrims, block, 0, st, dIn, (const unsigned int*)w.order.ptr, n, T);
+    }
+    hipLaunchKernelGGL(lbvhEmitTrianglesKernel, gridPrims, block, 0, st, dIn, finalOrder, un,
                        (RefPrimitiveAlign*)c->dRefPrims.ptr, (DevTriangle*)c->dTriangles.ptr, (DevShading*)c->dShading.ptr);
     HIP_TRY(hipGetLastError());
 
