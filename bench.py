@@ -139,14 +139,14 @@ def main():
     W, H, S = args.width, args.height, args.spp_per_step
     sr = ShardedRenderer(W, H, local_rank, rank, world)
     g = sr.renderer
+    if args.tuning:  # before the scene goes in: some settings steer the device BVH builder
+        g.set_tuning(**{k: int(v) for k, v in (item.split("=") for item in args.tuning.split(","))})
     install_scene(g, work)
     params = R.default_params(W, H)
     params.max_bounces = args.bounces
     if work["side"] > 1:  # pull the camera back and up so the whole grid is in view
         R.set_camera(params, (-2.5 - 1.1 * work["side"], 1.0 + 0.8 * work["side"], 0.0), (0.0, 0.0, 0.0), W, H)
     sr.set_params(params)
-    if args.tuning:
-        g.set_tuning(**{k: int(v) for k, v in (item.split("=") for item in args.tuning.split(","))})
 
     # traversal statistics of one step (untimed, counting build of the same kernel, same frames)
     sr.clear()

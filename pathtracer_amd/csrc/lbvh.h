@@ -1,20 +1,21 @@
 // BVH construction on the GPU for scenes where the reference's O(n log^2 n) sweep-SAH builder
-// (Source/PathTracer/BVH.cpp:91-238) takes minutes: a linear BVH over 63-bit Morton codes of the
-// triangle centroids.  The result is a different (lower quality) tree than BVH.cpp builds, so
-// images agree with the reference only up to exact-tie breaking; it is emitted both in the
-// reference's node/primitive layouts (for download and checking) and in the packed device layouts
-// the render kernels read.
+// (Source/PathTracer/BVH.cpp:91-238) takes minutes.  The result is a different tree than BVH.cpp
+// builds, so images agree with the reference only up to exact-tie breaking; it is emitted both in
+// the reference's node/primitive layouts (for download and checking) and in the packed device
+// layouts the render kernels read.
 //
-// Stages (one kernel each, all on the caller's stream):
+// Stages (all on the caller's stream):
 //   bounds   centroid bounds of the soup (wave reduction + order-preserving integer atomics)
 //   morton   63-bit code per triangle (21 bits per axis)
 //   sort     hipcub radix sort of (code, triangle index)
-//   tree     radix-tree topology, one thread per internal node (Karras 2012); equal codes are
-//            split by index so the tree is always well formed
+//   tree     topology over the sorted triangles: locally-ordered clustering (ploc.h, the default),
+//            or the radix tree of this file (Karras 2012: one thread per internal node, equal codes
+//            split by index) followed by
 //   fit      bottom-up boxes and heights: the second thread to arrive at a node continues upward
 //   emit     sub-trees of <= 4 triangles collapse into leaves (the reference's leaf size); kept
-//            nodes are numbered by prefix sums; reference-layout nodes, packed DevNodes and the
-//            reordered triangle / shading records are written
+//            nodes are numbered (depth-first rank for the clustered tree, prefix sums over the index
+//            order for the radix tree); reference-layout nodes, packed DevNodes and the reordered
+//            triangle / shading records are written
 #pragma once
 #include <hip/hip_runtime.h>
 

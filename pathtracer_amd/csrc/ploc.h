@@ -22,6 +22,8 @@ struct PlocNodes {
     int* height;    // n-1: interior levels below and including the node
     float* box;     // (2n-1) x 6
     int* position;  // 2n-1: first position of the node's triangles in the final order
+    int* kept;      // 2n-1: nodes of the sub-tree that stay interior nodes (more than kLbvhLeafMax triangles)
+    int* preorder;  // 2n-1: rank of the node among the kept nodes in depth-first order, left before right
 };
 
 __device__ __forceinline__ float plocArea(const float* a, const float* b)
@@ -48,6 +50,7 @@ __global__ void plocInitKernel(const RefPrimitiveAlign* __restrict__ prims, cons
     }
     clusterId[m] = m;
     N.size[m] = 1;
+    N.kept[m] = 0;
 }
 
 // nearest[i] = the position within `radius` of i whose union with cluster i has the smallest area.
@@ -110,7 +113,9 @@ __global__ void plocMergeKernel(const int* __restrict__ idIn, const float* __res
         id = n + k;
         N.left[k] = a;
         N.right[k] = o;
-        N.size[id] = N.size[a] + N.size[o];
+        const int size = N.size[a] + N.size[o];
+        N.size[id] = size;
+        N.kept[id] = (size > kLbvhLeafMax ? 1 : 0) + N.kept[a] + N.kept[o];
         const int ha = a < n ? 0 : N.height[a - n], ho = o < n ? 0 : N.height[o - n];
         N.height[k] = 1 + (ha > ho ? ha : ho);
         for (int c = 0; c < 6; c++) N.box[(size_t)id * 6 + c] = b[c];
@@ -120,7 +125,9 @@ __global__ void plocMergeKernel(const int* __restrict__ idIn, const float* __res
 }
 
 // Top-down over the nodes of one round (later rounds first): a node's triangles start where the
-// node starts, the right child's after the left child's.
+// node starts, the right child's after the left child's; likewise its rank in depth-first order,
+// which becomes the node's index in the packed array: the left child sits next to its parent and
+// a sub-tree is one contiguous run of records, as in the host packer's pre-order layout.
 __global__ void plocPositionKernel(int first, int count, int n, PlocNodes N)
 {
     const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -130,11 +137,15 @@ __global__ void plocPositionKernel(int first, int count, int n, PlocNodes N)
     const int a = N.left[k], o = N.right[k];
     N.position[a] = p;
     N.position[o] = p + N.size[a];
+    const int d = N.preorder[n + k];
+    N.preorder[a] = d + 1;
+    N.preorder[o] = d + 1 + N.kept[a];
 }
 
 // Into the arrays of lbvh.h: internal node k becomes index n-2-k (the root, created last, is 0),
 // leaf m becomes n-1 + its position in the final order.
-__global__ void plocRelabelKernel(int n, PlocNodes N, const unsigned int* __restrict__ order, unsigned int* finalOrder, LbvhTree T)
+__global__ void plocRelabelKernel(int n, PlocNodes N, const unsigned int* __restrict__ order, unsigned int* finalOrder, LbvhTree T,
+                                  unsigned int* packedAt)
 {
     const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (t < n) {  // leaf t
@@ -152,6 +163,7 @@ __global__ void plocRelabelKernel(int n, PlocNodes N, const unsigned int* __rest
         T.first[f] = N.position[id];
         T.last[f] = N.position[id] + N.size[id] - 1;
         T.height[f] = N.height[t];
+        packedAt[f] = (unsigned int)N.preorder[id];
         for (int c = 0; c < 6; c++) T.box[(size_t)f * 6 + c] = N.box[(size_t)id * 6 + c];
         T.parent[ua] = f;
         T.parent[uo] = f;

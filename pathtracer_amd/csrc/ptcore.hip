@@ -117,7 +117,7 @@ struct pt_ctx {
     // finished samples of one launch, 48 B per (sample, pixel); resolved into the images after the launch
     DeviceBuffer dSamples;
     uint64_t sampleBudgetBytes = 8ull << 30;
-    int plocRadius = 16;  // device BVH builder: neighbours searched on either side per clustering round (0: Morton radix tree)
+    int plocRadius = 32;  // device BVH builder: neighbours searched on either side per clustering round (0: Morton radix tree)
     bool deepStackInLds = false;  // trees deeper than 32 levels: whole stack in LDS (12/16 KB per wave)
     size_t waveTimeCount = 0;
     // geometry built on the device (pt_build_bvh_device): the tree in the reference's layouts, kept for
@@ -487,8 +487,9 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
         const dim3 grid((unsigned)gridBlocks), block(kMegaThreads);
         HIP_TRY(hipEventRecord(c->evTrace0, c->stream));
         // Trees up to 32 levels deep keep the whole traversal stack in LDS (8 KB per wave).  Deeper
-        // ones keep 32 entries there and the rest in private memory, or (deepStackInLds, for A/B) get
-        // a 12 or 16 KB LDS stack at the price of resident waves.
+        // ones keep 32 entries there and the rest in private memory (3 % slower than the all-LDS kernel
+        // on a 5 M-triangle scene whose tree is 34 deep; a 40-entry LDS stack, 15 waves per CU, costs
+        // 6 %, a 48-entry one 13 %), or (deepStackInLds, for A/B) get a 12 or 16 KB LDS stack.
         const int stackClass = c->maxDepth <= 32 ? 0 : (!c->deepStackInLds ? 3 : (c->maxDepth <= 48 ? 1 : 2));
 #define PT_LAUNCH_TRACE(COUNTED)                                                                                         \
     do {                                                                                                                 \
@@ -1257,12 +1258,12 @@ struct LbvhScratch {
     DeviceBuffer in, keys, keysSorted, values, order, sortTemp, parent, left, right, first, last, box, height, visits, emit,
         kept, emitAt, keptAt, scanTemp, bounds;
     // clustering builder (ploc.h)
-    DeviceBuffer pLeft, pRight, pSize, pHeight, pBox, pPosition, idA, idB, boxA, boxB, nearest, flags, scan, finalOrder;
+    DeviceBuffer pLeft, pRight, pSize, pHeight, pBox, pPosition, pKept, pPreorder, packedAt, idA, idB, boxA, boxB, nearest, flags, scan, finalOrder;
     ~LbvhScratch()
     {
         DeviceBuffer* all[] = {&in, &keys, &keysSorted, &values, &order, &sortTemp, &parent, &left, &right, &first, &last,
                                &box, &height, &visits, &emit, &kept, &emitAt, &keptAt, &scanTemp, &bounds,
-                               &pLeft, &pRight, &pSize, &pHeight, &pBox, &pPosition, &idA, &idB, &boxA, &boxB, &nearest,
+                               &pLeft, &pRight, &pSize, &pHeight, &pBox, &pPosition, &pKept, &pPreorder, &packedAt, &idA, &idB, &boxA, &boxB, &nearest,
                                &flags, &scan, &finalOrder};
         for (DeviceBuffer* b : all) b->release();
     }
@@ -1279,6 +1280,9 @@ int buildPlocTopology(pt_ctx* c, LbvhScratch& w, const RefPrimitiveAlign* dIn, i
     HIP_TRY(w.pHeight.ensure(internal * 4));
     HIP_TRY(w.pBox.ensure(2 * count * 24));
     HIP_TRY(w.pPosition.ensure(2 * count * 4));
+    HIP_TRY(w.pKept.ensure(2 * count * 4));
+    HIP_TRY(w.pPreorder.ensure(2 * count * 4));
+    HIP_TRY(w.packedAt.ensure(internal * 4));
     HIP_TRY(w.idA.ensure(count * 4));
     HIP_TRY(w.idB.ensure(count * 4));
     HIP_TRY(w.boxA.ensure(count * 24));
@@ -1290,7 +1294,8 @@ int buildPlocTopology(pt_ctx* c, LbvhScratch& w, const RefPrimitiveAlign* dIn, i
     hipStream_t st = c->stream;
     const dim3 block(256);
     auto grid = [](size_t items) { return dim3((unsigned int)((items + 255) / 256)); };
-    PlocNodes N{(int*)w.pLeft.ptr, (int*)w.pRight.ptr, (int*)w.pSize.ptr, (int*)w.pHeight.ptr, (float*)w.pBox.ptr, (int*)w.pPosition.ptr};
+    PlocNodes N{(int*)w.pLeft.ptr,     (int*)w.pRight.ptr, (int*)w.pSize.ptr,    (int*)w.pHeight.ptr, (float*)w.pBox.ptr,
+                (int*)w.pPosition.ptr, (int*)w.pKept.ptr,  (int*)w.pPreorder.ptr};
     int* idIn = (int*)w.idA.ptr;
     int* idOut = (int*)w.idB.ptr;
     float* boxIn = (float*)w.boxA.ptr;
@@ -1331,10 +1336,11 @@ int buildPlocTopology(pt_ctx* c, LbvhScratch& w, const RefPrimitiveAlign* dIn, i
     }
     if (created != n - 1) return fail(PT_ERR_DEVICE, "clustering builder lost nodes (internal error)");
     HIP_TRY(hipMemsetAsync((int*)w.pPosition.ptr + (n + n - 2), 0, 4, st));  // the root's triangles start at 0
+    HIP_TRY(hipMemsetAsync((int*)w.pPreorder.ptr + (n + n - 2), 0, 4, st));  // and the root is the first kept node
     for (size_t r = rounds.size(); r-- > 0;)
         hipLaunchKernelGGL(plocPositionKernel, grid((size_t)rounds[r].second), block, 0, st, rounds[r].first, rounds[r].second, n, N);
     hipLaunchKernelGGL(plocRelabelKernel, grid(count), block, 0, st, n, N, (const unsigned int*)w.order.ptr,
-                       (unsigned int*)w.finalOrder.ptr, T);
+                       (unsigned int*)w.finalOrder.ptr, T, (unsigned int*)w.packedAt.ptr);
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }
@@ -1393,7 +1399,8 @@ int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count)
     HIP_TRY(hipMemsetAsync(w.visits.ptr, 0, internal * 4, st));
     HIP_TRY(hipMemsetAsync(w.height.ptr, 0, internal * 4, st));
     const unsigned int* finalOrder = (const unsigned int*)w.order.ptr;
-    if (c->plocRadius > 0 && n > kLbvhLeafMax) {
+    const bool clustered = c->plocRadius > 0 && n > kLbvhLeafMax;
+    if (clustered) {
         int rc = buildPlocTopology(c, w, dIn, n, T);
         if (rc != PT_OK) return rc;
         finalOrder = (const unsigned int*)w.finalOrder.ptr;
@@ -1436,8 +1443,9 @@ int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count)
         HIP_TRY(c->dNodes.ensure(devNodeCount * sizeof(DevNode)));
         HIP_TRY(hipMemsetAsync(c->dRefNodes.ptr, 0, sizeof(RefNodeAlign), st));
         HIP_TRY(hipMemsetAsync(c->dNodes.ptr, 0, sizeof(DevNode), st));
+        // packed node index: depth-first rank for the clustered tree, index order for the radix tree
         hipLaunchKernelGGL(lbvhEmitNodesKernel, gridNodes, block, 0, st, n, T, (const unsigned int*)w.emitAt.ptr,
-                           (const unsigned int*)w.keptAt.ptr, (const unsigned int*)w.kept.ptr, (RefNodeAlign*)c->dRefNodes.ptr,
+                           (const unsigned int*)(clustered ? w.packedAt.ptr : w.keptAt.ptr), (const unsigned int*)w.kept.ptr, (RefNodeAlign*)c->dRefNodes.ptr,
                            (DevNode*)c->dNodes.ptr);
         HIP_TRY(hipGetLastError());
         c->rootRef = 1;
