@@ -191,7 +191,7 @@ int pt_process_buffers_full_sweep(pt_ctx* ctx);
 /* BVH construction on the GPU (no counterpart in the reference): Morton-sorted triangles are merged
  * bottom-up by locally-ordered clustering (nearest partner by surface area within a window of the
  * sorted order), sub-trees of at most 4 triangles become leaves.  Built for scenes where
- * BVH::BuildBvhWithSah's O(n log^2 n) sweep takes minutes (20 M triangles in 0.13 s including the
+ * BVH::BuildBvhWithSah's O(n log^2 n) sweep takes minutes (20 M triangles in 0.11 s including the
  * upload); the tree differs from the one BVH.cpp builds (its SAH cost is close to an uncapped sweep's,
  * far below the reference's capped one), images differ from the reference's only where distances
  * tie exactly.  prims112: `count` unsorted BvhPrimitiveAlign records (host memory); the call uploads

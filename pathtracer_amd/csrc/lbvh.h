@@ -61,13 +61,17 @@ __global__ void lbvhInitBoundsKernel(LbvhBounds* b)
 
 __global__ void lbvhBoundsKernel(const RefPrimitiveAlign* __restrict__ prims, unsigned int n, LbvhBounds* out)
 {
-    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // grid-stride: a few thousand blocks whatever n is, so the seven atomics per wave below stay few
     unsigned int lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u}, mesh = 0u;
-    if (i < n) {
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float c[3];
         lbvhCentroid(prims[i], c);
-        for (int k = 0; k < 3; k++) lo[k] = hi[k] = lbvhEncode(c[k]);
-        mesh = prims[i].meshIndex;
+        for (int k = 0; k < 3; k++) {
+            const unsigned int e = lbvhEncode(c[k]);
+            lo[k] = e < lo[k] ? e : lo[k];
+            hi[k] = e > hi[k] ? e : hi[k];
+        }
+        mesh = prims[i].meshIndex > mesh ? prims[i].meshIndex : mesh;
     }
     for (int off = 32; off > 0; off >>= 1) {
         for (int k = 0; k < 3; k++) {

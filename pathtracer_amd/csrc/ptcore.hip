@@ -1381,7 +1381,7 @@ int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count)
     const RefPrimitiveAlign* dIn = (const RefPrimitiveAlign*)w.in.ptr;
     HIP_TRY(hipMemcpyAsync(w.in.ptr, hostPrims, count * sizeof(RefPrimitiveAlign), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(lbvhInitBoundsKernel, dim3(1), dim3(64), 0, st, (LbvhBounds*)w.bounds.ptr);
-    hipLaunchKernelGGL(lbvhBoundsKernel, gridPrims, block, 0, st, dIn, un, (LbvhBounds*)w.bounds.ptr);
+    hipLaunchKernelGGL(lbvhBoundsKernel, dim3(std::min(gridPrims.x, 2048u)), block, 0, st, dIn, un, (LbvhBounds*)w.bounds.ptr);
     hipLaunchKernelGGL(lbvhMortonKernel, gridPrims, block, 0, st, dIn, un, (const LbvhBounds*)w.bounds.ptr,
                        (unsigned long long*)w.keys.ptr, (unsigned int*)w.values.ptr);
     HIP_TRY(hipGetLastError());
