@@ -4,7 +4,7 @@
 // the radiance image as PFM (float) and optionally as a tone-mapped PPM.
 //
 //   ptrender scene.glb [more.glb ...] [--width 1024] [--height 1024] [--spp 49] [--bounces 3]
-//            [--eye x y z] [--look-at x y z] [--fovy 1.57] [--device-bvh]
+//            [--eye x y z] [--look-at x y z] [--fovy 1.57] [--device-bvh | --full-sweep-bvh]
 //            [--hdri raw_f32_rgb_file width height] [--out render.pfm] [--ppm render.ppm]
 //
 // Materials come from ModelLoader::GenerateMaterial's mapping (pt_gltf_submesh_material); image
@@ -94,7 +94,7 @@ int main(int argc, char** argv)
     std::vector<std::string> files;
     int width = 1024, height = 1024, spp = 49, bounces = 3;  // the reference's defaults
     float eye[3] = {-2.5f, 1.0f, 0.0f}, center[3] = {0.0f, 0.0f, 0.0f}, fovy = 1.57f;
-    bool deviceBvh = false;
+    bool deviceBvh = false, fullSweepBvh = false;
     std::string out = "render.pfm", ppm, hdriPath;
     int hdriW = 1024, hdriH = 512;
     for (int i = 1; i < argc; i++) {
@@ -113,6 +113,7 @@ int main(int argc, char** argv)
         else if (a == "--eye") { need(3); for (float& e : eye) e = (float)std::atof(argv[++i]); }
         else if (a == "--look-at") { need(3); for (float& e : center) e = (float)std::atof(argv[++i]); }
         else if (a == "--device-bvh") deviceBvh = true;
+        else if (a == "--full-sweep-bvh") fullSweepBvh = true;
         else if (a == "--out") { need(1); out = argv[++i]; }
         else if (a == "--ppm") { need(1); ppm = argv[++i]; }
         else if (a == "--hdri") { need(3); hdriPath = argv[++i]; hdriW = std::atoi(argv[++i]); hdriH = std::atoi(argv[++i]); }
@@ -121,7 +122,7 @@ int main(int argc, char** argv)
     }
     if (files.empty() || width <= 0 || height <= 0 || spp <= 0) {
         std::fprintf(stderr, "usage: ptrender scene.glb [...] [--width W] [--height H] [--spp N] [--bounces B] [--eye x y z] "
-                             "[--look-at x y z] [--fovy f] [--device-bvh] [--hdri file w h] [--out x.pfm] [--ppm x.ppm]\n");
+                             "[--look-at x y z] [--fovy f] [--device-bvh | --full-sweep-bvh] [--hdri file w h] [--out x.pfm] [--ppm x.ppm]\n");
         return 2;
     }
 
@@ -155,7 +156,8 @@ int main(int argc, char** argv)
         }
         pt_gltf_free(g);
     }
-    PT(deviceBvh ? pt_process_buffers_device(ctx) : pt_process_buffers(ctx));
+    // the reference's builder bit for bit unless asked otherwise (both alternatives trace faster)
+    PT(deviceBvh ? pt_process_buffers_device(ctx) : (fullSweepBvh ? pt_process_buffers_full_sweep(ctx) : pt_process_buffers(ctx)));
 
     std::vector<float> hdri;
     if (hdriPath.empty()) {

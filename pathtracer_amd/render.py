@@ -45,6 +45,10 @@ def main(argv=None):
     ap.add_argument("--exr", default=None)
     ap.add_argument("--pfm", default=None)
     ap.add_argument("--aov-prefix", default=None, help="also write <prefix>albedo.png and <prefix>normal.png")
+    ap.add_argument("--bvh", choices=["reference", "full-sweep", "device"], default="reference",
+                    help="reference: the reference's sweep-SAH builder, bit for bit (cost cap included); full-sweep: the "
+                         "same sweep without the cap; device: built on the GPU (clustering).  The last two trace "
+                         "faster; images differ only where hit distances tie exactly")
     ap.add_argument("--checkpoint", default=None, help="save the accumulation images and the next FrameCount here (.npz)")
     ap.add_argument("--resume", default=None, help="continue from a --checkpoint file up to --spp (one GPU)")
     ap.add_argument("--device", type=int, default=None)
@@ -100,7 +104,10 @@ def main(argv=None):
         g.upload_texture(slot, texels, srgb)
     for (v, i), m in zip(meshes, mats):
         g.AddPathTracingModel(v, i, m)
-    g.ProcessBuffers()  # flatten -> sweep-SAH BVH -> aligned buffers -> upload
+    if args.bvh == "device":
+        g.ProcessBuffersDevice()
+    else:
+        g.ProcessBuffers(full_sweep=args.bvh == "full-sweep")  # flatten -> sweep-SAH BVH -> aligned buffers -> upload
     g.upload_environment(hdri)  # builds the importance-sampling cache on the host
     t_setup = time.time() - t0
     p = R.default_params(args.width, args.height)
