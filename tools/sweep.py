@@ -21,16 +21,22 @@ ap.add_argument("--bounces", type=int, default=8)
 ap.add_argument("--subdivide", type=int, default=bench.DEFAULT_SUBDIVIDE)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--bvh", choices=["host", "full-sweep", "device"], default="host")
 a = ap.parse_args()
 
 
 class A:
     subdivide = a.subdivide
+    bvh = a.bvh
 
 
 work = bench.build_workload(A)
 g = R.Renderer(a.width, a.height)
-g.upload_nodes(work["nodes"]); g.upload_primitives(work["prims"]); g.upload_materials(work["mats"])
+if work["nodes"] is None:
+    g.build_bvh_device(work["prims"])
+else:
+    g.upload_nodes(work["nodes"]); g.upload_primitives(work["prims"])
+g.upload_materials(work["mats"])
 g.upload_environment(work["hdri"], work["cache"])
 p = R.default_params(a.width, a.height)
 p.max_bounces = a.bounces
