@@ -12,12 +12,17 @@ from pathtracer_amd import renderer as R  # noqa: E402
 
 class A:
     subdivide = bench.DEFAULT_SUBDIVIDE
+    bvh = os.environ.get("PT_PROFILE_BVH", "host")  # host | full-sweep | device
 
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 work = bench.build_workload(A)
 g = R.Renderer(1920, 1080)
-g.upload_nodes(work["nodes"]); g.upload_primitives(work["prims"]); g.upload_materials(work["mats"])
+if work["nodes"] is None:
+    g.build_bvh_device(work["prims"])
+else:
+    g.upload_nodes(work["nodes"]); g.upload_primitives(work["prims"])
+g.upload_materials(work["mats"])
 g.upload_environment(work["hdri"], work["cache"])
 p = R.default_params(1920, 1080)
 p.max_bounces = 8
