@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--bvh", choices=["host", "full-sweep", "device"], default="host",
                     help="host: the reference's sweep-SAH builder (bit-identical tree); device: GPU linear BVH")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-device-tree", action="store_true",
+                    help="skip the extra measurement on the GPU-built tree (profiling runs: one tree per kernel name)")
     ap.add_argument("--tuning", default="", help="scheduler settings for A/B runs: key=value,key=value (Renderer.set_tuning)")
     args = ap.parse_args()
     if args.subdivide is None:
@@ -256,7 +258,7 @@ def main():
                         "the scene exceeds the 256 MB Infinity Cache: node and triangle fetches that miss L2 go to HBM",
             },
         }
-        if world == 1 and args.bvh == "host" and args.copies == 1:
+        if world == 1 and args.bvh == "host" and args.copies == 1 and not args.no_device_tree:
             # Outside the timed region, for the record: the same steps on the tree the GPU builder makes
             # of the same triangles (the reference's builder caps its split cost; see --bvh).
             try:
