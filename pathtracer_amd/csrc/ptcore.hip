@@ -1309,7 +1309,9 @@ int buildPlocTopology(pt_ctx* c, LbvhScratch& w, const RefPrimitiveAlign* dIn, i
     std::vector<std::pair<int, int>> rounds;  // (first node created, nodes created) per round
     int clusters = n, created = 0;
     while (clusters > 1) {
-        hipLaunchKernelGGL(plocNearestKernel, grid((size_t)clusters), block, 0, st, (const float*)boxIn, clusters, c->plocRadius,
+        // the fewer clusters are left, the higher in the tree the merges are and the cheaper a wide search is
+        const int radius = clusters < (1 << 16) ? std::max(c->plocRadius, 256) : (clusters < (1 << 20) ? std::max(c->plocRadius, 128) : c->plocRadius);
+        hipLaunchKernelGGL(plocNearestKernel, grid((size_t)clusters), block, 0, st, (const float*)boxIn, clusters, radius,
                            (int*)w.nearest.ptr);
         hipLaunchKernelGGL(plocFlagKernel, grid((size_t)clusters), block, 0, st, (const int*)w.nearest.ptr, clusters,
                            (unsigned long long*)w.flags.ptr);
