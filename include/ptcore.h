@@ -128,6 +128,12 @@ int pt_upload_nodes(pt_ctx* ctx, const void* nodes48, size_t count);
 /* SSBO binding 3 (PathTracingRenderer.cpp:615-662): BvhPrimitiveAlign records of 112 B in
  * post-build order. */
 int pt_upload_primitives(pt_ctx* ctx, const void* prims112, size_t count);
+/* No counterpart in the reference.  With enable != 0 the tree handed to pt_upload_nodes is checked
+ * but not traversed: the GPU builder (pt_build_bvh_device) makes its own over the primitives of
+ * pt_upload_primitives at the next dispatch.  For a host that keeps calling the reference's
+ * BVH::BuildBvhWithSah, whose capped split cost gives trees that take 2-3x the node visits per ray:
+ * one call, no other change, images equal except where hit distances tie exactly.  Off by default. */
+int pt_set_bvh_rebuild(pt_ctx* ctx, int enable);
 /* SSBO binding 1 (PathTracingRenderer.cpp:509-564): MaterialAlign records of 176 B.  The 11
  * 64-bit bindless handles are reinterpreted as 1-based slots of pt_upload_texture
  * (0 = no texture, as in the reference). */

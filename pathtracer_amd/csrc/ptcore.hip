@@ -117,6 +117,7 @@ struct pt_ctx {
     // finished samples of one launch, 48 B per (sample, pixel); resolved into the images after the launch
     DeviceBuffer dSamples;
     uint64_t sampleBudgetBytes = 8ull << 30;
+    bool rebuildOnUpload = false;  // pt_upload_nodes' tree is replaced by the device builder's over the same primitives
     int plocRadius = 32;  // device BVH builder: neighbours searched on either side per clustering round (0: Morton radix tree)
     bool deepStackInLds = false;  // trees deeper than 32 levels: whole stack in LDS (12/16 KB per wave)
     size_t waveTimeCount = 0;
@@ -160,6 +161,8 @@ struct DeviceGuard {
 
 float4* imagePtr(pt_ctx* c, int which) { return c->bound[which] ? c->bound[which] : (float4*)c->dImages[which].ptr; }
 
+int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count);
+
 int syncScene(pt_ctx* c)
 {
     if (!c->deviceGeometry && (c->nodes.empty() || c->prims.empty()))
@@ -176,6 +179,13 @@ int syncScene(pt_ctx* c)
         std::string err = PackScene(c->nodes.data(), c->nodes.size(), c->prims.data(), c->prims.size(),
                                     c->materials.size(), packed);
         if (!err.empty()) return fail(PT_ERR_SCENE, err);
+        if (c->rebuildOnUpload) {
+            // the uploaded tree was only validated; the device builder's tree over the same primitives is used
+            std::vector<RefPrimitiveAlign> prims;
+            prims.swap(c->prims);  // buildLbvh drops the host copies
+            const int rc = buildLbvh(c, prims.data(), prims.size());
+            return rc == PT_OK ? syncScene(c) : rc;
+        }
         if (packed.maxDepth > 64)
             return fail(PT_ERR_SCENE, "BVH is " + std::to_string(packed.maxDepth) + " interior levels deep; the traversal stack holds 64");
         const size_t nb = packed.nodes.size() * sizeof(DevNode), tb = packed.triangles.size() * sizeof(DevTriangle),
@@ -660,6 +670,13 @@ int pt_upload_primitives(pt_ctx* c, const void* prims112, size_t count)
     c->prims.assign(p, p + count);
     c->geometryDirty = true;
     c->deviceGeometry = false;
+    return PT_OK;
+}
+
+int pt_set_bvh_rebuild(pt_ctx* c, int enable)
+{
+    if (!c) return fail(PT_ERR_INVALID, "null context");
+    c->rebuildOnUpload = enable != 0;
     return PT_OK;
 }
 

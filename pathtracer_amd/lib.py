@@ -78,6 +78,7 @@ SYMBOLS = {
                                     ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     "pt_clear_models": (ctypes.c_int, [ctypes.c_void_p]),
     "pt_process_buffers": (ctypes.c_int, [ctypes.c_void_p]),
+    "pt_set_bvh_rebuild": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pt_process_buffers_full_sweep": (ctypes.c_int, [ctypes.c_void_p]),
     "pt_build_bvh_full_sweep": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
                                                ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),

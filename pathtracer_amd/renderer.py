@@ -92,6 +92,10 @@ class Renderer:
     def ClearPathTracingModels(self):
         check(self._lib.pt_clear_models(self._h))
 
+    def set_bvh_rebuild(self, enable=True):
+        """Uploaded trees are replaced by the GPU builder's over the same primitives (see pt_set_bvh_rebuild)."""
+        check(self._lib.pt_set_bvh_rebuild(self._h, int(bool(enable))))
+
     def ProcessBuffers(self, full_sweep=False):
         """full_sweep: the sweep-SAH builder without the reference's cost cap (a different, better tree)."""
         check((self._lib.pt_process_buffers_full_sweep if full_sweep else self._lib.pt_process_buffers)(self._h))

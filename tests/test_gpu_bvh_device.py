@@ -125,3 +125,39 @@ def test_full_sweep_tree_renders_like_the_oracle_and_like_the_reference_tree():
     for a, b in zip(images[False], images[True]):
         differing = int(np.any(a.view(np.uint32) != b.view(np.uint32), axis=-1).sum())
         assert differing <= 1e-4 * width * height, differing
+
+
+def test_rebuild_on_upload_keeps_the_image_and_cuts_the_visits():
+    """pt_set_bvh_rebuild: the reference's tree is uploaded as usual, the device builder's tree over the
+    same primitives is traversed.  Same image (up to exact distance ties), fewer node visits per ray."""
+    from tests.common import built_scene
+    nodes, prims, mats = built_scene("BunnyGlass")
+    hdri, cache = environment(256, 128)
+    width, height = 160, 128
+    p = R.default_params(width, height)
+    p.max_bounces = 8
+    images, visits = {}, {}
+    for rebuild in (False, True):
+        g = R.Renderer(width, height)
+        g.set_bvh_rebuild(rebuild)
+        g.upload_nodes(nodes)
+        g.upload_primitives(prims)
+        g.upload_materials(mats)
+        g.upload_environment(hdri, cache)
+        g.set_params(p)
+        g.clear()
+        g.dispatch(1, 2, 1, counted=True)
+        images[rebuild] = [g.read_image(k) for k in range(3)]
+        st = g.stats()
+        visits[rebuild] = st.node_visits / (st.rays_closest + st.rays_any)
+        if rebuild:  # the tree in use can be read back, and new materials do not undo it
+            got_nodes, got_prims = g.download_bvh()
+            assert got_prims.shape[0] == prims.shape[0] and got_nodes.shape[0] != nodes.shape[0]
+            g.upload_materials(mats)
+            g.clear()
+            g.dispatch(1, 2, 1)
+            assert g.read_image(0).tobytes() == images[True][0].tobytes()
+    for a, b in zip(images[False], images[True]):
+        differing = int(np.any(a.view(np.uint32) != b.view(np.uint32), axis=-1).sum())
+        assert differing <= 1e-4 * width * height, differing
+    assert visits[True] < 0.6 * visits[False], visits
