@@ -29,6 +29,8 @@ cache = R.calculate_hdri_cache(hdri)
 
 def run(name, width, height, bounces, meshes, mats, textures=(), eye=None, look_at=(0.0, 0.0, 0.0)):
     g = R.Renderer(width, height)
+    if args.tuning:  # before the scene goes in: some settings steer the device BVH builder
+        g.set_tuning(**{k: int(v) for k, v in (item.split("=") for item in args.tuning.split(","))})
     for slot, texels, srgb in textures:
         g.upload_texture(slot, texels, srgb)
     for (v, i), m in zip(meshes, mats):
@@ -43,8 +45,6 @@ def run(name, width, height, bounces, meshes, mats, textures=(), eye=None, look_
     if eye is not None:
         R.set_camera(p, eye, look_at, width, height)
     g.set_params(p)
-    if args.tuning:
-        g.set_tuning(**{k: int(v) for k, v in (item.split("=") for item in args.tuning.split(","))})
     g.clear()
     g.dispatch(1, args.spp, 1)  # warm-up: also measures the tile costs the next launches are ordered by
     g.synchronize()
