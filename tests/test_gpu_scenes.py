@@ -14,7 +14,7 @@ import pytest
 from pathtracer_amd import gltf
 from pathtracer_amd import renderer as R
 from pathtracer_amd import scenes
-from tests.common import built_meshes
+from tests.common import built_meshes, environment
 from tests.test_gpu_parity import PIPELINES, _assert_images_equal, _pair
 
 pytestmark = pytest.mark.gpu
@@ -107,3 +107,35 @@ def test_converged_images_agree_within_rmse():
     rmse = np.sqrt(np.mean((a - b) ** 2)) / max(np.mean(b), 1e-9)
     assert rmse < 0.02, rmse
     assert abs(gpu.mean() / cpu.mean() - 1.0) < 0.005
+
+
+def test_three_builders_one_image():
+    """Mill through the reference's builder, the uncapped sweep and the GPU builder: the closest hit does
+    not depend on the tree, so the three images are equal (a difference could only come from two
+    triangles hit at exactly the same distance)."""
+    s = gltf.GltfScene.from_npz(os.path.join(SCENES, "mill.npz"))
+    mats, textures = s.materials()
+    hdri, cache = environment(256, 128)
+    p = R.default_params(200, 120)
+    R.set_camera(p, (14.0, 9.0, 16.0), (0.0, 5.0, 0.0), 200, 120, fovy=1.0)
+    p.max_bounces = 6
+    images = []
+    for how in ("reference", "full-sweep", "device"):
+        g = R.Renderer(200, 120)
+        for slot, texels, srgb in textures:
+            g.upload_texture(slot, texels, srgb)
+        for (v, i), m in zip(s.submeshes, mats):
+            g.AddPathTracingModel(v, i, m)
+        if how == "device":
+            g.ProcessBuffersDevice()
+        else:
+            g.ProcessBuffers(full_sweep=how == "full-sweep")
+        g.upload_environment(hdri, cache)
+        g.set_params(p)
+        g.clear()
+        g.dispatch(1, 4, 1)
+        images.append([g.read_image(k) for k in range(3)])
+    for other in images[1:]:
+        for a, b in zip(images[0], other):
+            differing = int(np.any(a.view(np.uint32) != b.view(np.uint32), axis=-1).sum())
+            assert differing <= 1e-4 * 200 * 120, differing
