@@ -483,9 +483,10 @@ __global__ void fillBlocksKernel(const unsigned* __restrict__ order, const unsig
     if (i == tiles - 1) *blockCount = first + n < capacity ? first + n : capacity;
 }
 
-// STACK entries of traversal stack per lane in LDS, DEEP more in private memory (0: none).
-template <int STACK, int DEEP, bool COUNT>
-__global__ __launch_bounds__(kMegaThreads, PT_WAVES_PER_SIMD) void renderKernel(DevParams P, DevScene S, Images img, DevCounters* counters)
+// STACK entries of traversal stack per lane in LDS, DEEP more in private memory (0: none); compiled
+// for WAVES resident waves per SIMD (4: 128 VGPRs, 3: 168 VGPRs and a quarter of the spills).
+template <int STACK, int DEEP, bool COUNT, int WAVES = PT_WAVES_PER_SIMD>
+__global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P, DevScene S, Images img, DevCounters* counters)
 {
     static_assert(kMegaThreads == 64, "one wave per block: the sample pool below is wave-wide");
     __shared__ int s_stack[STACK * kMegaThreads];

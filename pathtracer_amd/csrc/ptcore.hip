@@ -117,6 +117,8 @@ struct pt_ctx {
     // finished samples of one launch, 48 B per (sample, pixel); resolved into the images after the launch
     DeviceBuffer dSamples;
     uint64_t sampleBudgetBytes = 8ull << 30;
+    bool qualityTree = false;  // the tree in use was built by this library's own builders (uncapped sweep, device)
+    int wavesPerSimd = 0;      // megakernel variant: 3 or 4 waves per SIMD, 0 = by qualityTree
     bool rebuildOnUpload = false;  // pt_upload_nodes' tree is replaced by the device builder's over the same primitives
     int plocRadius = 32;  // device BVH builder: neighbours searched on either side per clustering round (0: Morton radix tree)
     bool deepStackInLds = false;  // trees deeper than 32 levels: whole stack in LDS (12/16 KB per wave)
@@ -433,6 +435,8 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
         // the lower bound itself, or half of it for images with no more tiles than wave slots (swept at
         // 512 x 512, 720p and 1080p with 16 and 64 frames per launch), unless set by hand.
         const unsigned split = c->tileSplit >= 0 ? (unsigned)c->tileSplit : (tiles <= c->waveSlots ? 2u : 1u);
+        // (waveSlots counts four waves per SIMD; the three-wave variant holds three quarters of that, which
+        // only makes the cap a little finer)
         const size_t capacity = tiles + (size_t)split * c->waveSlots;
         if (c->tileCostTiles != tiles || c->blockCapacity != capacity) {
             for (DeviceBuffer* b : {&c->dTileCost, &c->dTileParts, &c->dTileKey, &c->dTileKeySorted, &c->dTileIds, &c->dTileOrder,
@@ -501,11 +505,18 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
         // on a 5 M-triangle scene whose tree is 34 deep; a 40-entry LDS stack, 15 waves per CU, costs
         // 6 %, a 48-entry one 13 %), or (deepStackInLds, for A/B) get a 12 or 16 KB LDS stack.
         const int stackClass = c->maxDepth <= 32 ? 0 : (!c->deepStackInLds ? 3 : (c->maxDepth <= 48 ? 1 : 2));
+        // Three waves per SIMD (more registers, a quarter of the spills) for trees built by this library's
+        // own builders, four for uploaded ones: with few node visits per ray the shading blocks, where the
+        // spills are, weigh more (8.7 % faster at three on the benchmark scene's device-built tree, 0.8 %
+        // slower on the reference's tree of the same scene).
+        const bool three = c->wavesPerSimd == 3 || (c->wavesPerSimd == 0 && c->qualityTree);
 #define PT_LAUNCH_TRACE(COUNTED)                                                                                         \
     do {                                                                                                                 \
-        if (stackClass == 3) hipLaunchKernelGGL((renderKernel<32, 32, COUNTED>), grid, block, 0, c->stream, P, S, img, ctr);      \
+        if (stackClass == 3 && three) hipLaunchKernelGGL((renderKernel<32, 32, COUNTED, 3>), grid, block, 0, c->stream, P, S, img, ctr); \
+        else if (stackClass == 3) hipLaunchKernelGGL((renderKernel<32, 32, COUNTED>), grid, block, 0, c->stream, P, S, img, ctr); \
         else if (stackClass == 2) hipLaunchKernelGGL((renderKernel<64, 0, COUNTED>), grid, block, 0, c->stream, P, S, img, ctr); \
         else if (stackClass == 1) hipLaunchKernelGGL((renderKernel<48, 0, COUNTED>), grid, block, 0, c->stream, P, S, img, ctr); \
+        else if (three) hipLaunchKernelGGL((renderKernel<32, 0, COUNTED, 3>), grid, block, 0, c->stream, P, S, img, ctr);        \
         else hipLaunchKernelGGL((renderKernel<32, 0, COUNTED>), grid, block, 0, c->stream, P, S, img, ctr);                      \
     } while (0)
         if (counted) PT_LAUNCH_TRACE(true);
@@ -658,6 +669,7 @@ int pt_upload_nodes(pt_ctx* c, const void* nodes48, size_t count)
     c->nodes.assign(p, p + count);
     c->geometryDirty = true;
     c->deviceGeometry = false;
+    c->qualityTree = false;
     c->tileCostValid = false;
     return PT_OK;
 }
@@ -804,6 +816,7 @@ int processBuffers(pt_ctx* c, bool uncapped)
     if (rc != PT_OK) return rc;
     rc = pt_upload_nodes(c, nodesAligned.data(), nodesAligned.size());
     if (rc != PT_OK) return rc;
+    c->qualityTree = uncapped;
     return pt_upload_primitives(c, primsAligned.data(), primsAligned.size());
 }
 
@@ -1151,7 +1164,8 @@ int pt_scene_bytes(pt_ctx* c, uint64_t* nodeBytes, uint64_t* triangleBytes, uint
 // -1: chosen from the number of tiles per wave slot); 8: sample-buffer budget in MiB (a dispatch is
 // cut into launches whose sample records fit); 9: trees deeper than 32 levels keep their whole traversal
 // stack in LDS (1) instead of 32 entries there and the rest in private memory (0, the default); 10: device BVH
-// builder: clustering search radius (0 = Morton radix tree).
+// builder: clustering search radius (0 = Morton radix tree); 11: megakernel compiled for 3 or 4 waves per SIMD
+// (0 = 3 for trees of this library's own builders, 4 for uploaded ones).
 int pt_debug_set_tuning(pt_ctx* c, int key, int value)
 {
     if (!c) return fail(PT_ERR_INVALID, "null context");
@@ -1191,6 +1205,10 @@ int pt_debug_set_tuning(pt_ctx* c, int key, int value)
     case 9:
         if (value != 0 && value != 1) return fail(PT_ERR_INVALID, "deep_stack_in_lds must be 0 or 1");
         c->deepStackInLds = value != 0;
+        return PT_OK;
+    case 11:
+        if (value != 0 && value != 3 && value != 4) return fail(PT_ERR_INVALID, "waves per SIMD must be 0 (automatic), 3 or 4");
+        c->wavesPerSimd = value;
         return PT_OK;
     case 10:
         if (value < 0 || value > 256) return fail(PT_ERR_INVALID, "clustering radius must be 0..256");
@@ -1482,6 +1500,7 @@ int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count)
     c->maxDepth = height;
     c->tileCostValid = false;
     c->deviceGeometry = true;
+    c->qualityTree = c->plocRadius > 0;
     c->geometryDirty = false;
     c->nodes.clear();
     c->prims.clear();
