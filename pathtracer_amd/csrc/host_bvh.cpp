@@ -180,10 +180,42 @@ struct Builder {
         out[id] = node;
     }
 
+    // Large ranges of the uncapped builder: 16 equal chunks sorted on their own threads, then merged
+    // pairwise.  The chunking does not depend on the machine, so the order of equal centroids (and
+    // with it the tree) does not either.  The capped builder keeps the single std::sort whose handling
+    // of equal keys the reference's tree depends on.
+    template <class Less>
+    static void chunkedSort(Key* first, Key* last, Less less)
+    {
+        constexpr int kChunks = 16;
+        const size_t n = (size_t)(last - first);
+        size_t edge[kChunks + 1];
+        for (int k = 0; k <= kChunks; k++) edge[k] = n * (size_t)k / kChunks;
+        std::vector<std::thread> pool;
+        for (int k = 0; k < kChunks; k++) pool.emplace_back([=] { std::sort(first + edge[k], first + edge[k + 1], less); });
+        for (std::thread& t : pool) t.join();
+        for (int width = 1; width < kChunks; width *= 2) {
+            pool.clear();
+            for (int k = 0; k + width < kChunks; k += 2 * width) {
+                const int hi = k + 2 * width < kChunks ? k + 2 * width : kChunks;
+                pool.emplace_back([=] { std::inplace_merge(first + edge[k], first + edge[k + width], first + edge[hi], less); });
+            }
+            for (std::thread& t : pool) t.join();
+        }
+    }
+
     void sortAxis(int l, int r, int axis) const
     {
         Key* first = keys.data() + l;
         Key* last = keys.data() + r + 1;
+        if (kInf > kRefInf && r - l + 1 >= (1 << 18)) {
+            switch (axis) {
+            case 0: chunkedSort(first, last, [](const Key& a, const Key& b) { return a.c[0] < b.c[0]; }); break;
+            case 1: chunkedSort(first, last, [](const Key& a, const Key& b) { return a.c[1] < b.c[1]; }); break;
+            default: chunkedSort(first, last, [](const Key& a, const Key& b) { return a.c[2] < b.c[2]; }); break;
+            }
+            return;
+        }
         switch (axis) {
         case 0: std::sort(first, last, [](const Key& a, const Key& b) { return a.c[0] < b.c[0]; }); break;
         case 1: std::sort(first, last, [](const Key& a, const Key& b) { return a.c[1] < b.c[1]; }); break;
