@@ -132,3 +132,22 @@ def test_full_sweep_builder_gives_a_valid_and_cheaper_tree(recipe):
     # deterministic across thread counts like the capped builder
     again, nodes_again = R.build_bvh_sah(prims100, 4, full_sweep=True)
     assert nodes_again.tobytes() == nodes_full.tobytes() and again.tobytes() == sorted_full.tobytes()
+
+
+def test_full_sweep_builder_large_input_takes_the_chunked_sort():
+    """Ranges of 2^18 keys and more are sorted in chunks on several threads in the uncapped builder.
+    270 000 random triangles: the tree is valid, and two builds give the same bytes."""
+    from tests.common import check_tree
+    rng = np.random.default_rng(3)
+    n = 270_000
+    centre = rng.uniform(-10, 10, (n, 1, 3)).astype(np.float32)
+    tri = centre + rng.uniform(-0.05, 0.05, (n, 3, 3)).astype(np.float32)
+    v = np.zeros((n * 3, 8), np.float32)
+    v[:, :3] = tri.reshape(-1, 3)
+    v[:, 4] = 1.0
+    prims100 = R.assemble_primitives(v, np.arange(n * 3, dtype=np.uint32), 0)
+    sorted_prims, nodes = R.build_bvh_sah(prims100, 4, full_sweep=True)
+    depth, _ = check_tree(R.align_nodes(nodes), R.align_primitives(sorted_prims), R.align_primitives(prims100))
+    assert depth < 40
+    again_prims, again_nodes = R.build_bvh_sah(prims100, 4, full_sweep=True)
+    assert again_nodes.tobytes() == nodes.tobytes() and again_prims.tobytes() == sorted_prims.tobytes()
