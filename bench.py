@@ -1,23 +1,31 @@
 #!/usr/bin/env python3
 """Benchmark of the path-tracing hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--spp-per-step S]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--spp-per-step S] [--scene NAME]
 
-Workload: the reference's "DragonGlass" scene at 1920x1080, max 8 bounces.  The reference's
-Dragon.glb is not available, so the DragonGlass material recipe
-(PathTracingApplication.cpp:693-714) is applied to bunny.glb, midpoint-subdivided once to 576 k
-triangles (the order of the missing dragon mesh), + Floor.glb; the HDRI is the analytic
-sky of pathtracer_amd.scenes (all reference HDRIs but a 1x1 black one are missing).  Data: synthetic.
+Headline workload (--scene dragonglass, the default): the reference's "DragonGlass" scene at
+1920x1080, max 8 bounces.  The reference's Dragon.glb is not available, so the DragonGlass material
+recipe (PathTracingApplication.cpp:693-714) is applied to bunny.glb, midpoint-subdivided once to
+576 k triangles (the order of the missing dragon mesh), + Floor.glb; the HDRI is the analytic sky of
+pathtracer_amd.scenes (all reference HDRIs but a 1x1 black one are missing).  Data: synthetic.
+Other scenes: `interior` (closed textured room lit through a window and by an emissive panel: the
+stand-in for the Fireplace scene), `spheres` (sphere field, 65 materials, 16 bounces), `c1`
+(BunnyClearcoat 512x512, 3 bounces: the reference's default scene at its default size).
 
 A step is one pt_dispatch of S samples per pixel over the whole frame (S consecutive FrameCount
-values of this rank's shard; the default 4 steps x 64 spp make up the config's 256 spp), followed for N > 1 by the RCCL sum-reduce of the three accumulation
-buffers.  Ranks shard by sample index (rank r renders FrameCount r+1, r+1+N, ...); the scene is
-replicated; per-GPU work is fixed as N grows (weak scaling).  value = rays traced by all ranks /
-max-over-ranks wall time, rays = closest-hit + shadow BVH queries counted by the kernel.
+values of this rank's shard; the default 4 steps x 64 spp make up the config's 256 spp).  Ranks shard
+by sample index (rank r renders FrameCount r+1, r+1+N, ...); the scene is replicated; per-GPU work is
+fixed as N grows (weak scaling); for N > 1 the K steps are one render and end, inside the timed
+region, in the one RCCL sum-reduce of the three accumulation buffers.  value = rays traced by all
+ranks / max-over-ranks wall time, rays = closest-hit + shadow BVH queries counted by the kernel.
+
+`--gpus N` without a torchrun environment starts the N ranks itself (one process per GPU).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,7 +35,9 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+L2_PEAK_GBS = 34500.0   # aggregate of the eight per-XCD L2s, measured
+MALL_GATHER_GBS = 8600.0  # measured ceiling for random rows served by the Infinity Cache
 # The reference's Dragon.glb is missing; the Stanford dragon it is commonly built from has ~871 k
 # triangles.  The bunny (144 k) subdivided once (576 k) is the closest stand-in at hand.
 DEFAULT_SUBDIVIDE = 1
@@ -37,25 +47,45 @@ DEFAULT_SUBDIVIDE = 1
 # RGBA32F texels read + written) per pixel and launch.
 S_NODE, S_TRI, S_SHADE, S_MAT, S_SAMPLE, S_ACC = 64, 48, 64, 80, 48, 96
 
+SCENES = {  # name -> (metric label, default width, height, bounces)
+    "dragonglass": ("1080p DragonGlass", 1920, 1080, 8),
+    "interior": ("1080p interior (Fireplace stand-in)", 1920, 1080, 8),
+    "spheres": ("1080p sphere field", 1920, 1080, 16),
+    "c1": ("512x512 BunnyClearcoat", 512, 512, 3),
+}
+
 
 def build_workload(args):
     """Scene buffers in the reference's layouts.  With --bvh device the nodes are left out: the
     unsorted soup goes to the GPU builder (install_scene)."""
+    from pathtracer_amd import recipes, scenes
     from pathtracer_amd import renderer as R
-    from pathtracer_amd import scenes
+    scene = getattr(args, "scene", "dragonglass")
     copies = getattr(args, "copies", 1)
-    side = 1
-    if copies > 1:
+    side, textures, camera = 1, [], None
+    if scene == "interior":
+        meshes, mats, textures, _ = recipes.load_scene("Interior")
+        camera = recipes.INTERIOR_CAMERA
+    elif scene == "spheres":
+        meshes, mats = scenes.sphere_field()
+        camera = dict(eye=(-14.0, 7.0, 0.0), look_at=(0.0, 0.0, 0.0))
+    elif scene == "c1":
+        meshes, mats = scenes.flatten(scenes.recipe("BunnyClearcoat"))
+    elif copies > 1:
         meshes, mats, side = scenes.instanced_bunnies(copies)
     else:
         meshes, mats = scenes.flatten(scenes.recipe("DragonGlass"))
-    if args.subdivide > 0:
+    subdivide = getattr(args, "subdivide", 0) or 0
+    if subdivide > 0:
         v, i = meshes[0]
-        meshes[0] = scenes.subdivide(v, i, args.subdivide)
+        meshes[0] = scenes.subdivide(v, i, subdivide)
+    if side > 1:  # pull the camera back and up so the whole grid is in view
+        camera = dict(eye=(-2.5 - 1.1 * side, 1.0 + 0.8 * side, 0.0), look_at=(0.0, 0.0, 0.0))
     prims = np.concatenate([R.assemble_primitives(v, i, k) for k, (v, i) in enumerate(meshes)])
     hdri = scenes.sky_hdri(1024, 512)
     cache = R.calculate_hdri_cache(hdri)
-    work = dict(mats=mats, hdri=hdri, cache=cache, triangles=int(prims.shape[0]), side=side)
+    work = dict(mats=mats, hdri=hdri, cache=cache, triangles=int(prims.shape[0]), side=side, textures=textures,
+                camera=camera, scene=scene)
     if getattr(args, "bvh", "host") == "device":
         work.update(nodes=None, prims=R.align_primitives(prims), bvh_seconds=None)
     else:
@@ -66,6 +96,8 @@ def build_workload(args):
 
 
 def install_scene(g, work):
+    for slot, texels, srgb in work.get("textures", []):
+        g.upload_texture(slot, texels, srgb)
     if work["nodes"] is None:
         t0 = time.time()
         g.build_bvh_device(work["prims"])
@@ -78,26 +110,124 @@ def install_scene(g, work):
     g.upload_environment(work["hdri"], work["cache"])
 
 
-def cpu_baseline(work, params, width, height, threads):
-    """The CPU oracle (a scalar restatement of the reference shader, kind "port") on one full
-    frame (FrameCount 1) of the same workload."""
+def scene_params(work, width, height, bounces):
+    from pathtracer_amd import renderer as R
+    params = R.default_params(width, height)
+    params.max_bounces = bounces
+    if work.get("camera"):
+        R.set_camera(params, work["camera"]["eye"], work["camera"]["look_at"], width, height)
+    return params
+
+
+def cpu_baseline(work, params, width, height, threads, frames=None):
+    """The CPU oracle (a scalar restatement of the reference shader, kind "port") on whole frames
+    (FrameCount 1..n) of the same workload: n = `frames`, or as many as take about 15 s."""
     from oracle import binding as ob
     o = ob.Oracle()
     o.set_scene(work["nodes"], work["prims"], work["mats"])
+    for slot, texels, srgb in work.get("textures", []):
+        o.set_texture(slot, texels, srgb)
     o.set_environment(work["hdri"], work["cache"])
-    # calibrate on one frame, then size the sample to about 15 s of CPU work
-    t0 = time.time()
-    o.render(params, width, height, 1, 1, 1, threads=threads)
-    t1 = time.time() - t0
-    frames = int(max(1, min(256, round(15.0 / max(t1, 1e-3)))))
+    if frames is None:  # calibrate on one frame, then size the sample to about 15 s of CPU work
+        t0 = time.time()
+        o.render(params, width, height, 1, 1, 1, threads=threads)
+        t1 = time.time() - t0
+        frames = int(max(1, min(256, round(15.0 / max(t1, 1e-3)))))
     t0 = time.time()
     _, _, _, _, ctr = o.render(params, width, height, 1, frames, 1, threads=threads)
     dt = time.time() - t0
     rays = ctr.rays_closest + ctr.rays_any
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
             "sample": (f"{frames} spp (FrameCount 1..{frames}) of the full {width}x{height} frame, "
                        f"{rays} rays in {dt:.1f} s"),
-            "spp_per_s": frames / dt}
+            "spp_per_s": frames / dt, "seconds": dt,
+            # the shader's own traversal (no pruning, 48-B nodes fetched one by one, 112-B primitives)
+            "reference_traversal": {"node_fetches_per_ray": ctr.node_fetches / max(rays, 1),
+                                    "pair_tests_per_ray": ctr.pair_tests / max(rays, 1),
+                                    "triangle_tests_per_ray": ctr.triangle_tests / max(rays, 1),
+                                    "reference_layout_bytes_per_ray": (48 * ctr.node_fetches + 112 * ctr.triangle_tests) / max(rays, 1),
+                                    "max_stack_occupancy": int(ctr.max_stack), "stack_overflows": int(ctr.stack_overflows)}}
+
+
+class StubShardedRenderer:
+    """Stands in for ShardedRenderer under --stub (launcher and reduction logic on CPU, gloo): renders
+    nothing, counts two rays per sample, keeps the three images as a CPU tensor of sample counts."""
+
+    class _Stats:
+        rays_closest = rays_any = samples = node_visits = triangle_tests = closest_hits = max_stack_depth = 0
+
+    def __init__(self, width, height, rank, world):
+        self.width, self.height, self.rank, self.world = width, height, rank, world
+        self.images = torch.zeros(3, height, width, 4)
+        self.total = self.images.clone()
+        self.renderer = self
+        self._last = self._Stats()
+
+    def set_params(self, params):
+        pass
+
+    def clear(self):
+        self.images.zero_()
+
+    def render_step(self, step, spp, counted=False):
+        self.images += float(spp)
+        s = self._Stats()
+        s.samples = self.width * self.height * spp
+        s.rays_closest, s.rays_any = s.samples, s.samples
+        s.node_visits, s.triangle_tests, s.closest_hits = 10 * s.samples, 2 * s.samples, s.samples // 2
+        self._last = s
+
+    def reduce(self):
+        import torch.distributed as dist
+        self.total.copy_(self.images)
+        if self.world > 1:
+            dist.all_reduce(self.total, op=dist.ReduceOp.SUM)
+
+    def stats(self):
+        return self._last
+
+    def synchronize(self):
+        pass
+
+    def last_kernel_ms(self):
+        return 1.0, 0.1
+
+    def scene_bytes(self):
+        return 0, 0, 0
+
+
+def self_launch(args, argv):
+    """`--gpus N` outside a torchrun environment: start N ranks (one process per GPU) as a child
+    torch.distributed.run, which must happen before this process touches the GPU, and pass its exit
+    code on; rank 0 of the child prints the line."""
+    if not args.stub:
+        have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible", file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd)
+
+
+def pmc_summary(args, W, H, S):
+    """Counter-derived figures of the trace kernel from the committed rocprofv3 PMC summary, valid
+    only for the launch shape they were collected on."""
+    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        t = json.load(open(path))
+    except Exception:
+        return None
+    shape = (t.get("scene"), t.get("width"), t.get("height"), t.get("spp_per_step"), t.get("max_bounces"), t.get("subdivide"),
+             t.get("bvh"), t.get("copies"))
+    if shape != (args.scene, W, H, S, args.bounces, args.subdivide, args.bvh, args.copies):
+        return None
+    return t
 
 
 def main():
@@ -106,52 +236,69 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp-per-step", type=int, default=64)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--scene", choices=sorted(SCENES), default="dragonglass")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--bounces", type=int, default=None)
     ap.add_argument("--subdivide", type=int, default=None,
-                    help="midpoint-subdivide the bunny this many times (default 1: 576 k triangles; 0 with --copies)")
+                    help="midpoint-subdivide the first mesh this many times (dragonglass default 1: 576 k triangles; 0 with --copies)")
     ap.add_argument("--copies", type=int, default=1,
                     help="instanced-scene stress: this many bunnies flattened on a jittered grid (139 = 20 M triangles)")
     ap.add_argument("--bvh", choices=["host", "full-sweep", "device"], default="host",
-                    help="host: the reference's sweep-SAH builder (bit-identical tree); device: GPU linear BVH")
+                    help="host: the reference's sweep-SAH builder (bit-identical tree); device: GPU builder")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-device-tree", action="store_true",
                     help="skip the extra measurement on the GPU-built tree (profiling runs: one tree per kernel name)")
+    ap.add_argument("--reduce-every-step", action="store_true", help="N > 1: all-reduce after every step, not once per render")
     ap.add_argument("--tuning", default="", help="scheduler settings for A/B runs: key=value,key=value (Renderer.set_tuning)")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # launcher test on CPU: gloo, no renderer
     args = ap.parse_args()
+    label, dw, dh, db = SCENES[args.scene]
+    W = args.width or dw
+    H = args.height or dh
+    args.bounces = args.bounces or db
     if args.subdivide is None:
-        args.subdivide = DEFAULT_SUBDIVIDE if args.copies == 1 else 0
+        args.subdivide = DEFAULT_SUBDIVIDE if (args.scene == "dragonglass" and args.copies == 1) else 0
+    S = args.spp_per_step
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     distributed = world > 1
-    torch.cuda.set_device(local_rank)
+    if not args.stub:
+        torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.stub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from pathtracer_amd import renderer as R
-    from pathtracer_amd.distributed import ShardedRenderer
+    def sync():
+        if not args.stub:
+            torch.cuda.synchronize()
 
-    work = build_workload(args)
-    W, H, S = args.width, args.height, args.spp_per_step
-    sr = ShardedRenderer(W, H, local_rank, rank, world)
-    g = sr.renderer
-    if args.bvh == "full-sweep" and "waves_per_simd" not in args.tuning:
-        # an uploaded tree gets the four-wave kernel; this one is known to be a good tree (see the tuning key)
-        args.tuning = (args.tuning + "," if args.tuning else "") + "waves_per_simd=3"
-    if args.tuning:  # before the scene goes in: some settings steer the device BVH builder
-        g.set_tuning(**{k: int(v) for k, v in (item.split("=") for item in args.tuning.split(","))})
-    install_scene(g, work)
-    params = R.default_params(W, H)
-    params.max_bounces = args.bounces
-    if work["side"] > 1:  # pull the camera back and up so the whole grid is in view
-        R.set_camera(params, (-2.5 - 1.1 * work["side"], 1.0 + 0.8 * work["side"], 0.0), (0.0, 0.0, 0.0), W, H)
-    sr.set_params(params)
+    if args.stub:
+        work = dict(triangles=0, bvh_seconds=0.0, side=1)
+        sr = StubShardedRenderer(W, H, rank, world)
+        g, params = sr, None
+    else:
+        from pathtracer_amd.distributed import ShardedRenderer
+        work = build_workload(args)
+        sr = ShardedRenderer(W, H, local_rank, rank, world)
+        g = sr.renderer
+        if args.bvh == "full-sweep" and "waves_per_simd" not in args.tuning:
+            # an uploaded tree gets the four-wave kernel; this one is known to be a good tree (see the tuning key)
+            args.tuning = (args.tuning + "," if args.tuning else "") + "waves_per_simd=3"
+        if args.tuning:  # before the scene goes in: some settings steer the device BVH builder
+            g.set_tuning(**{k: int(v) for k, v in (item.split("=") for item in args.tuning.split(","))})
+        install_scene(g, work)
+        params = scene_params(work, W, H, args.bounces)
+        sr.set_params(params)
 
     # traversal statistics of one step (untimed, counting build of the same kernel, same frames)
     sr.clear()
@@ -169,29 +316,33 @@ def main():
     for w in range(args.warmup):
         sr.render_step(w, S)
         sr.reduce()
-    torch.cuda.synchronize()
+    sync()
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     rays = 0
     kernel_ms = []
     t0 = time.perf_counter()
     for k in range(args.steps):
         sr.render_step(k, S)
-        sr.reduce()
+        if args.reduce_every_step:
+            sr.reduce()
         # counters and event times are read after the stream work of this step was queued; reading
         # them synchronises this rank's stream (part of the measured time, as a real caller would)
         s = g.stats()
         rays += s.rays_closest + s.rays_any
         kernel_ms.append(g.last_kernel_ms())
-    torch.cuda.synchronize()
+    if not args.reduce_every_step:
+        sr.reduce()  # one collective per render (the K steps)
+    sync()
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
 
     if distributed:
-        t = torch.tensor([elapsed, float(rays)], device="cuda", dtype=torch.float64)
+        dev = "cpu" if args.stub else "cuda"
+        t = torch.tensor([elapsed, float(rays)], device=dev, dtype=torch.float64)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -202,19 +353,26 @@ def main():
         avg_kernel_s = float(np.mean([t for t, _ in kernel_ms])) / 1e3
         avg_resolve_s = float(np.mean([r for _, r in kernel_ms])) / 1e3
         achieved = bytes_per_launch / avg_kernel_s / 1e9
-        # PMC-measured bytes per launch, valid only for the launch shape it was collected on
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                t = json.load(open(tpath))
-                if (t.get("width"), t.get("height"), t.get("spp_per_step"), t.get("max_bounces")) == (W, H, S, args.bounces) \
-                        and args.copies == 1 and args.bvh == "host" and args.subdivide == t.get("subdivide"):
-                    traffic = t.get("bytes_per_launch")
-            except Exception:
-                traffic = None
+        scene_bytes = int(sum(g.scene_bytes()))
+        cache_resident = scene_bytes < 256e6
+        pmc = None if args.stub else pmc_summary(args, W, H, S)
+        traffic = pmc.get("bytes_per_launch") if pmc else None
+        if args.copies > 1:
+            what = f"DragonGlass recipe on {args.copies} flattened bunnies + floor ({work['triangles']} triangles), "
+            label = f"{W}x{H} DragonGlass on {work['triangles'] / 1e6:.0f} M triangles"
+        elif args.scene == "dragonglass":
+            what = f"DragonGlass recipe on bunny.glb (subdivided x{args.subdivide}) + Floor.glb stand-in ({work['triangles']} triangles), "
+        elif args.scene == "interior":
+            what = (f"interior stand-in for the Fireplace scene: closed textured room with one window, AreaLight and Mill content "
+                    f"({work['triangles']} triangles), ")
+        elif args.scene == "spheres":
+            what = f"sphere field, 64 spheres with 65 seeded materials ({work['triangles']} triangles), "
+        else:
+            what = f"BunnyClearcoat recipe on bunny.glb + Floor.glb ({work['triangles']} triangles), "
+        if (W, H) != (dw, dh) and args.copies == 1:
+            label = label.replace("1080p", f"{W}x{H}").replace("512x512", f"{W}x{H}")
         out = {
-            "metric": "Mrays/s at 1080p DragonGlass (closest-hit + shadow BVH queries per second)",
+            "metric": f"Mrays/s at {label} (closest-hit + shadow BVH queries per second)",
             "value": rays / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -229,23 +387,35 @@ def main():
             "spp_per_s": total_spp / elapsed,
             "msamples_per_s": total_spp * W * H / elapsed / 1e6,
             "config": {
-                "workload": ((f"DragonGlass recipe on bunny.glb (subdivided x{args.subdivide}) + Floor.glb stand-in ({work['triangles']} triangles), "
-                              if args.copies == 1 else
-                              f"DragonGlass recipe on {args.copies} flattened bunnies + floor ({work['triangles']} triangles), ") +
-                             f"{W}x{H}, max {args.bounces} bounces, {S} spp per step per GPU, analytic sky HDRI 1024x512, "
-                             "BVH built by the " + {"device": "GPU linear-BVH builder", "host": "sweep-SAH host builder (the reference tree)",
+                "workload": ("stub renderer (launcher test)" if args.stub else
+                             what + f"{W}x{H}, max {args.bounces} bounces, {S} spp per step per GPU, analytic sky HDRI 1024x512, "
+                             "BVH built by the " + {"device": "GPU clustering builder", "host": "sweep-SAH host builder (the reference tree)",
                                                       "full-sweep": "sweep-SAH host builder without the reference's cost cap"}[args.bvh]),
-                "width": W, "height": H, "max_bounces": args.bounces, "spp_per_step_per_gpu": S,
+                "scene": args.scene, "width": W, "height": H, "max_bounces": args.bounces, "spp_per_step_per_gpu": S,
                 "total_spp": total_spp, "parallelism": f"sample-sharded x{world}" if world > 1 else "single GPU",
+                "reduce": ("none (one GPU)" if world == 1 else
+                           "one RCCL all-reduce per step" if args.reduce_every_step else "one RCCL all-reduce per render (after the last step, timed)"),
                 "bvh_build_seconds": round(work["bvh_seconds"], 3),
             },
             "roofline": {
-                "bound": "hbm",
+                # `achieved` / `frac` are ALGORITHMIC bytes over the trace kernel's HIP-event time against the HBM peak.
+                # What the counters say bounds the kernel is `bound` (from the committed PMC summary of this launch shape).
+                "bound": (pmc.get("bound") if pmc and pmc.get("bound") else ("hbm" if not cache_resident else "valu-issue")),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "level": "L2 + Infinity Cache (scene cache resident)" if cache_resident else "HBM (scene exceeds the 256 MB Infinity Cache)",
+                "frac_l2": achieved / L2_PEAK_GBS,
+                "fabric_gbps": (traffic / avg_kernel_s / 1e9) if traffic else None,
+                "fabric_frac": ((traffic / avg_kernel_s / 1e9) / (MALL_GATHER_GBS if cache_resident else HBM_PEAK_GBS)) if traffic else None,
+                "fabric_peak": MALL_GATHER_GBS if cache_resident else HBM_PEAK_GBS,
+                "valu_busy": pmc.get("valu_busy") if pmc else None,
+                "lane_utilisation": pmc.get("lane_utilisation") if pmc else None,
+                "waves_per_simd": pmc.get("waves_per_simd") if pmc else None,
+                "l2_hit": pmc.get("l2_hit") if pmc else None,
+                "pmc_source": pmc.get("source") if pmc else None,
                 "kernel": "renderKernel",
                 "kernel_ms_avg": avg_kernel_s * 1e3,
                 "algorithmic_bytes_per_ray": bytes_per_ray,
@@ -253,15 +423,13 @@ def main():
                 "node_visits_per_ray": st.node_visits / rays_step,
                 "triangle_tests_per_ray": st.triangle_tests / rays_step,
                 "max_stack_depth": st.max_stack_depth,
-                "scene_bytes": int(sum(g.scene_bytes())),
+                "scene_bytes": scene_bytes,
                 "resolve_kernel": {"kernel_ms_avg": avg_resolve_s * 1e3, "algorithmic_bytes": resolve_bytes,
-                                   "achieved": resolve_bytes / avg_resolve_s / 1e9, "unit": "GB/s"},
-                "note": ("the scene fits the 256 MB Infinity Cache, so algorithmic bytes are served by L1/L2/Infinity Cache; "
-                         "the fraction is of the HBM peak as the contract asks") if sum(g.scene_bytes()) < 256e6 else
-                        "the scene exceeds the 256 MB Infinity Cache: node and triangle fetches that miss L2 go to HBM",
+                                   "achieved": resolve_bytes / avg_resolve_s / 1e9, "unit": "GB/s", "bound": "hbm",
+                                   "frac": resolve_bytes / avg_resolve_s / 1e9 / HBM_PEAK_GBS},
             },
         }
-        if world == 1 and args.bvh == "host" and args.copies == 1 and not args.no_device_tree:
+        if world == 1 and args.bvh == "host" and args.copies == 1 and not args.no_device_tree and not args.stub:
             # Outside the timed region, for the record: the same steps on the tree the GPU builder makes
             # of the same triangles (the reference's builder caps its split cost; see --bvh).
             try:
@@ -282,10 +450,11 @@ def main():
                                             "bvh_build_seconds": round(t_build, 3)}
             except Exception as e:  # never lose the benchmark line over the extra measurement
                 out["device_built_tree"] = {"error": str(e)}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not args.stub:
             threads = min(16, os.cpu_count() or 1)
             try:
-                out["cpu_baseline"] = cpu_baseline(work, params, W, H, threads)
+                # c1 is the configuration the CPU baseline is defined on: all of its 64 spp (about 40 M rays)
+                out["cpu_baseline"] = cpu_baseline(work, params, W, H, threads, frames=64 if args.scene == "c1" else None)
             except Exception as e:  # the oracle library is a test artefact: report, do not lose the line
                 out["cpu_baseline"] = {"error": str(e)}
         print(json.dumps(out))

@@ -5,7 +5,7 @@
 //
 //   ptrender scene.glb [more.glb ...] [--width 1024] [--height 1024] [--spp 49] [--bounces 3]
 //            [--eye x y z] [--look-at x y z] [--fovy 1.57] [--device-bvh | --full-sweep-bvh]
-//            [--hdri raw_f32_rgb_file width height] [--out render.pfm] [--ppm render.ppm]
+//            [--hdri raw_f32_rgb_file width height] [--out render.pfm] [--ppm display.ppm] [--exposure 1.0]
 //
 // Materials come from ModelLoader::GenerateMaterial's mapping (pt_gltf_submesh_material); image
 // textures are skipped with a warning, because decoding PNG/JPEG is the host's job (stb_image in
@@ -71,29 +71,13 @@ std::vector<float> MakeSky(int width, int height)
     return rgb;
 }
 
-// Shaders/tonemapping.frag:21-71: ACES fit (input and output matrices around the rational curve), then sRGB
-void Tonemap(const float in[3], unsigned char out[3])
-{
-    static const float mi[3][3] = {{0.59719f, 0.35458f, 0.04823f}, {0.07600f, 0.90834f, 0.01566f}, {0.02840f, 0.13383f, 0.83777f}};
-    static const float mo[3][3] = {{1.60475f, -0.53108f, -0.07367f}, {-0.10208f, 1.10813f, -0.00605f}, {-0.00327f, -0.07276f, 1.07602f}};
-    float a[3], b[3];
-    for (int r = 0; r < 3; r++) a[r] = mi[r][0] * in[0] + mi[r][1] * in[1] + mi[r][2] * in[2];
-    for (int r = 0; r < 3; r++) a[r] = (a[r] * (a[r] + 0.0245786f) - 0.000090537f) / (a[r] * (0.983729f * a[r] + 0.4329510f) + 0.238081f);
-    for (int r = 0; r < 3; r++) b[r] = mo[r][0] * a[0] + mo[r][1] * a[1] + mo[r][2] * a[2];
-    for (int r = 0; r < 3; r++) {
-        float c = b[r] < 0.0f ? 0.0f : (b[r] > 1.0f ? 1.0f : b[r]);
-        c = c <= 0.0031308f ? c * 12.92f : 1.055f * std::pow(c, 1.0f / 2.4f) - 0.055f;
-        out[r] = (unsigned char)(c * 255.0f + 0.5f);
-    }
-}
-
 }  // namespace
 
 int main(int argc, char** argv)
 {
     std::vector<std::string> files;
     int width = 1024, height = 1024, spp = 49, bounces = 3;  // the reference's defaults
-    float eye[3] = {-2.5f, 1.0f, 0.0f}, center[3] = {0.0f, 0.0f, 0.0f}, fovy = 1.57f;
+    float eye[3] = {-2.5f, 1.0f, 0.0f}, center[3] = {0.0f, 0.0f, 0.0f}, fovy = 1.57f, exposure = 1.0f;
     bool deviceBvh = false, fullSweepBvh = false;
     std::string out = "render.pfm", ppm, hdriPath;
     int hdriW = 1024, hdriH = 512;
@@ -116,13 +100,14 @@ int main(int argc, char** argv)
         else if (a == "--full-sweep-bvh") fullSweepBvh = true;
         else if (a == "--out") { need(1); out = argv[++i]; }
         else if (a == "--ppm") { need(1); ppm = argv[++i]; }
+        else if (a == "--exposure") { need(1); exposure = (float)std::atof(argv[++i]); }
         else if (a == "--hdri") { need(3); hdriPath = argv[++i]; hdriW = std::atoi(argv[++i]); hdriH = std::atoi(argv[++i]); }
         else if (a.rfind("--", 0) == 0) { std::fprintf(stderr, "ptrender: unknown option %s\n", a.c_str()); return 2; }
         else files.push_back(a);
     }
     if (files.empty() || width <= 0 || height <= 0 || spp <= 0) {
         std::fprintf(stderr, "usage: ptrender scene.glb [...] [--width W] [--height H] [--spp N] [--bounces B] [--eye x y z] "
-                             "[--look-at x y z] [--fovy f] [--device-bvh | --full-sweep-bvh] [--hdri file w h] [--out x.pfm] [--ppm x.ppm]\n");
+                             "[--look-at x y z] [--fovy f] [--device-bvh | --full-sweep-bvh] [--hdri file w h] [--out x.pfm] [--ppm x.ppm] [--exposure e]\n");
         return 2;
     }
 
@@ -196,15 +181,14 @@ int main(int argc, char** argv)
     std::fprintf(f, "PF\n%d %d\n-1.0\n", width, height);
     std::fwrite(rgb.data(), 4, rgb.size(), f);
     std::fclose(f);
-    if (!ppm.empty()) {
+    if (!ppm.empty()) {  // the reference's display pass (exposure 1, ACES fit, sRGB encoding), done on the device
+        std::vector<unsigned char> display((size_t)width * height * 3);
+        PT(pt_read_display(ctx, exposure, display.data()));
         f = std::fopen(ppm.c_str(), "wb");
         if (!f) { std::fprintf(stderr, "ptrender: cannot write %s\n", ppm.c_str()); return 1; }
         std::fprintf(f, "P6\n%d %d\n255\n", width, height);
-        std::vector<unsigned char> row((size_t)width * 3);
-        for (int y = height - 1; y >= 0; y--) {
-            for (int x = 0; x < width; x++) Tonemap(&rgb[((size_t)y * width + x) * 3], &row[(size_t)x * 3]);
-            std::fwrite(row.data(), 1, row.size(), f);
-        }
+        for (int y = height - 1; y >= 0; y--)  // PPM rows run top to bottom
+            std::fwrite(display.data() + (size_t)y * width * 3, 1, (size_t)width * 3, f);
         std::fclose(f);
     }
     std::printf("ptrender: %zu triangles, %dx%d, %d spp, %d bounces: %.2f ms on the GPU, %.0f Mrays/s -> %s\n", triangles, width,

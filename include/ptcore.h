@@ -89,7 +89,9 @@ typedef struct pt_params {
     uint32_t accumulate_mode; /* PT_ACCUM_*                                                   */
 } pt_params;
 
-/* Counters of the most recent pt_dispatch_counted() (all zero after pt_dispatch()). */
+/* Counters of the most recent dispatch.  samples, rays_closest, rays_any and closest_hits are kept by
+ * every dispatch (pt_dispatch, pt_dispatch_counted); node_visits, triangle_tests and
+ * max_stack_depth only by pt_dispatch_counted() and are zero after the others. */
 typedef struct pt_stats {
     uint64_t samples;         /* (pixel, FrameCount) pairs traced                        */
     uint64_t rays_closest;    /* closest-hit BVH queries                                 */
@@ -289,6 +291,13 @@ int pt_write_image(pt_ctx* ctx, int which, const float* rgba);
  * buffer the reference hands to its denoiser for colour, albedo and normal (:101-155).  Copies
  * width*height*3 floats; synchronises the stream. */
 int pt_read_image_rgb(pt_ctx* ctx, int which, float* rgb_out);
+/* The reference's display pass over the radiance image: PostFXRenderPass with Shaders/tonemapping.frag
+ * (:21-71: exposure, fitted ACES curve, clamp) drawn into the default framebuffer with
+ * GL_FRAMEBUFFER_SRGB enabled (Runtime/Renderer/Renderer.cpp:25; the pass is installed at
+ * PathTracingRenderer.cpp:85-86), read back as 8-bit RGB: width*height*3 bytes, row 0 = GL row 0
+ * (the bottom row when displayed).  `exposure` is the Exposure uniform (PathTracingApplication.h
+ * default 1.0).  Runs on the device; synchronises the stream. */
+int pt_read_display(pt_ctx* ctx, float exposure, unsigned char* rgb8_out);
 int pt_get_stats(pt_ctx* ctx, pt_stats* out);
 /* Milliseconds spent by the device in the most recent dispatch (HIP events on the context's
  * stream); synchronises. */

@@ -43,6 +43,8 @@ def oracle_lib():
                                       ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         lib.oracle_eval_math.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
+        lib.oracle_display.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_float, ctypes.c_void_p]
+        lib.oracle_display.restype = None
         lib.oracle_fnv1a64.restype = ctypes.c_uint64
         lib.oracle_fnv1a64.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_uint64]
         assert lib.oracle_sizeof_counters() == ctypes.sizeof(OracleCounters)
@@ -65,6 +67,30 @@ def ref_lib():
     return _ref
 
 
+REF_HDRI_PATH = os.path.join(_HERE, "_ref", "libref_hdri.so")
+_ref_hdri = None
+
+
+def ref_hdri_lib():
+    """Lines 803-901 of the reference's PathTracingRenderer.cpp (CalculateHdriCache's arithmetic)
+    compiled in place; None when not built."""
+    global _ref_hdri
+    if _ref_hdri is None and os.path.exists(REF_HDRI_PATH):
+        lib = ctypes.CDLL(REF_HDRI_PATH)
+        lib.ref_calculate_hdri_cache.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        lib.ref_calculate_hdri_cache.restype = None
+        _ref_hdri = lib
+    return _ref_hdri
+
+
+def ref_calculate_hdri_cache(hdri_rgb):
+    a = np.ascontiguousarray(hdri_rgb, dtype=np.float32)
+    h, w = a.shape[:2]
+    out = np.zeros_like(a)
+    ref_hdri_lib().ref_calculate_hdri_cache(_ptr(a), w, h, _ptr(out))
+    return out
+
+
 def ref_build_bvh_sah(prims100, leaf_size=4):
     lib = ref_lib()
     p = np.ascontiguousarray(prims100, dtype=np.float32).copy()
@@ -80,6 +106,14 @@ def calculate_hdri_cache(hdri_rgb):
     h, w = a.shape[:2]
     out = np.zeros_like(a)
     oracle_lib().oracle_calculate_hdri_cache(_ptr(a), w, h, _ptr(out))
+    return out
+
+
+def display(rgba, exposure=1.0):
+    """(h, w, 4) float32 radiance -> (h, w, 3) uint8 through the reference's display pass."""
+    a = np.ascontiguousarray(rgba, dtype=np.float32)
+    out = np.empty(a.shape[:-1] + (3,), np.uint8)
+    oracle_lib().oracle_display(_ptr(a), a.size // 4, float(exposure), _ptr(out))
     return out
 
 

@@ -11,6 +11,9 @@
 // this file follows the shader text line by line and nothing executable confirms it.  The BVH
 // builder IS pinned: the reference's own BVH.cpp is compiled unmodified into
 // oracle/_ref/libref_shim.so (see Makefile) and the product's builder must match it bit for bit.
+// The HDRI-cache builder below IS pinned too: lines 803-901 of the reference's
+// PathTracingRenderer.cpp are compiled in place into oracle/_ref/libref_hdri.so and this file's
+// restatement (and the product's) must reproduce every float of the cache.
 //
 // Each function cites the reference lines it restates (paths relative to
 // Source/PathTracer/Shaders/ unless noted).  Arithmetic is IEEE binary32, one rounding per
@@ -23,6 +26,12 @@
 //     write lands in spare slots, the pixel is flagged in `overflow_mask`, and tests exclude it;
 //   * texture(): bilinear, REPEAT, base level, float weights
 //     (x = u*W - 0.5, i0 = floor(x), a = x - i0, texel indices wrapped modulo W).
+//   * min(x, y) / max(x, y) with a NaN operand (GLSL 4.60 section 8.3 leaves the result undefined;
+//     its formula min = y < x ? y : x would return x) -> the other operand, and -0 orders below +0
+//     (IEEE 754-2019 minimumNumber / maximumNumber, which is what v_min_f32 / v_max_f32 compute on
+//     gfx950).  It matters in HitAABB (intersection.glsl:63-77): a ray that lies in a slab plane with a
+//     zero direction component yields 0 * inf = NaN for that slab, and this choice drops the slab from
+//     the test instead of turning the whole box into a miss or a hit by operand order;
 //   * the dead primary trace at pathtracing.comp:237 has no observable effect and is not run.
 #include <atomic>
 #include <cmath>
@@ -1302,6 +1311,37 @@ void oracle_eval_math(int fn, const float* a, const float* b, float* out, long n
         case 8: out[i] = gl_sqrt(a[i]); break;
         default: out[i] = gl_inversesqrt(a[i]); break;
         }
+    }
+}
+
+// The display pass: tonemapping.frag:36-71 (main -> ACESFitted -> RRTAndODTFit; `color * mat3(a, b, c)`
+// is a row vector times a matrix with columns a, b, c; sums left to right) followed by the sRGB
+// encoding of GL_FRAMEBUFFER_SRGB (Runtime/Renderer/Renderer.cpp:25; OpenGL 4.6 section 17.3.7) and
+// round-to-nearest conversion to 8-bit unorm.  rgba: n RGBA32F texels; out: n x 3 bytes.
+static float display_channel(float c)
+{
+    c = gl_clamp(c, 0.0f, 1.0f);
+    const float e = c <= 0.0031308f ? c * 12.92f : 1.055f * gl_pow(c, 0.41666f) - 0.055f;
+    return std::floor(gl_clamp(e, 0.0f, 1.0f) * 255.0f + 0.5f);
+}
+void oracle_display(const float* rgba, long n, float exposure, unsigned char* out)
+{
+    for (long i = 0; i < n; i++) {
+        const float r = rgba[4 * i] * exposure, g = rgba[4 * i + 1] * exposure, b = rgba[4 * i + 2] * exposure;
+        float c[3] = {(r * 0.59719f + g * 0.35458f) + b * 0.04823f, (r * 0.07600f + g * 0.90834f) + b * 0.01566f,
+                      (r * 0.02840f + g * 0.13383f) + b * 0.83777f};
+        for (int k = 0; k < 3; k++) {  // RRTAndODTFit, tonemapping.frag:36-41
+            const float v = c[k];
+            const float a = v * (v + 0.0245786f) - 0.000090537f;
+            const float d = v * (0.983729f * v + 0.4329510f) + 0.238081f;
+            c[k] = a / d;
+        }
+        const float x = (c[0] * 1.60475f + c[1] * -0.53108f) + c[2] * -0.07367f;
+        const float y = (c[0] * -0.10208f + c[1] * 1.10813f) + c[2] * -0.00605f;
+        const float z = (c[0] * -0.00327f + c[1] * -0.07276f) + c[2] * 1.07602f;
+        out[3 * i] = (unsigned char)display_channel(x);
+        out[3 * i + 1] = (unsigned char)display_channel(y);
+        out[3 * i + 2] = (unsigned char)display_channel(z);
     }
 }
 

@@ -408,17 +408,25 @@ std::string LoadGltf(const std::string& path, GltfScene& scene)
         }
         const Json* norm = a.find("normalized");
         v.normalized = norm && norm->type == Json::Bool && norm->b;
-        v.count = (size_t)getInt(a, "count", 0);
+        // Every number below comes from the file: reject negative values before any of them is cast, and
+        // phrase the range check so that no sum or product can wrap.
+        const int64_t count = getInt(a, "count", 0), byteStride = getInt(bv, "byteStride", 0);
+        const int64_t viewOffset = getInt(bv, "byteOffset", 0), viewLength = getInt(bv, "byteLength", 0);
+        const int64_t accessorOffset = getInt(a, "byteOffset", 0);
+        if (count < 0 || byteStride < 0 || viewOffset < 0 || viewLength < 0 || accessorOffset < 0)
+            return std::string(what) + ": negative count, stride, offset or length";
+        v.count = (size_t)count;
         const size_t elemBytes = compBytes * (size_t)v.components;
-        const int64_t byteStride = getInt(bv, "byteStride", 0);
         v.stride = byteStride > 0 ? (size_t)byteStride : elemBytes;
-        const size_t start = (size_t)getInt(bv, "byteOffset", 0) + (size_t)getInt(a, "byteOffset", 0);
-        const size_t viewEnd = (size_t)getInt(bv, "byteOffset", 0) + (size_t)getInt(bv, "byteLength", 0);
         const std::vector<uint8_t>& buf = buffers[(size_t)bufIndex];
-        if (v.count > 0) {
-            const size_t last = start + (v.count - 1) * v.stride + elemBytes;
-            if (last > buf.size() || last > viewEnd) return std::string(what) + ": accessor reads past its buffer view";
-        }
+        // the view must lie inside the buffer, the accessor's elements inside the view
+        if ((size_t)viewOffset > buf.size() || (size_t)viewLength > buf.size() - (size_t)viewOffset)
+            return std::string(what) + ": bufferView outside its buffer";
+        if ((size_t)accessorOffset > (size_t)viewLength) return std::string(what) + ": accessor reads past its buffer view";
+        const size_t start = (size_t)viewOffset + (size_t)accessorOffset;
+        const size_t room = (size_t)viewLength - (size_t)accessorOffset;  // bytes from `start` to the view's end
+        if (v.count > 0 && (elemBytes > room || (v.count - 1) > (room - elemBytes) / v.stride))
+            return std::string(what) + ": accessor reads past its buffer view";
         v.base = buf.data() + start;
         return std::string();
     };
@@ -452,9 +460,12 @@ std::string LoadGltf(const std::string& path, GltfScene& scene)
             if (viewIndex < 0 || (size_t)viewIndex >= jViews.size()) return "image " + std::to_string(i) + " has neither uri nor bufferView";
             const Json& bv = jViews[(size_t)viewIndex];
             const int64_t bufIndex = getInt(bv, "buffer", -1);
-            const size_t off = (size_t)getInt(bv, "byteOffset", 0), len = (size_t)getInt(bv, "byteLength", 0);
-            if (bufIndex < 0 || (size_t)bufIndex >= buffers.size() || off + len > buffers[(size_t)bufIndex].size())
+            const int64_t offSigned = getInt(bv, "byteOffset", 0), lenSigned = getInt(bv, "byteLength", 0);
+            if (bufIndex < 0 || (size_t)bufIndex >= buffers.size() || offSigned < 0 || lenSigned < 0 ||
+                (size_t)offSigned > buffers[(size_t)bufIndex].size() ||
+                (size_t)lenSigned > buffers[(size_t)bufIndex].size() - (size_t)offSigned)
                 return "image " + std::to_string(i) + ": bufferView outside its buffer";
+            const size_t off = (size_t)offSigned, len = (size_t)lenSigned;
             img.bytes.assign(buffers[(size_t)bufIndex].begin() + (std::ptrdiff_t)off, buffers[(size_t)bufIndex].begin() + (std::ptrdiff_t)(off + len));
         }
     }

@@ -1068,6 +1068,53 @@ __global__ void packRgbKernel(const float4* __restrict__ in, float* __restrict__
     }
 }
 
+// Display transform of the reference's post-processing pass: exposure, the fitted ACES curve
+// (Shaders/tonemapping.frag:21-71; `color * mat3(a, b, c)` is a row vector times a matrix whose
+// columns are a, b, c, so component i is dot(color, column i)), then the sRGB encoding the reference
+// gets from GL_FRAMEBUFFER_SRGB on its default framebuffer (Runtime/Renderer/Renderer.cpp:25) and
+// the conversion to 8-bit unorm.  Sums run left to right; pow_ is the fixed-polynomial power of
+// device_math.h, so the bytes are reproducible on a CPU.
+PT_DEV float displayChannel(float c)
+{
+    c = clamp_(c, 0.0f, 1.0f);
+    const float e = c <= 0.0031308f ? c * 12.92f : 1.055f * pow_(c, 0.41666f) - 0.055f;  // GL 4.6 section 17.3.7
+    return __builtin_floorf(clamp_(e, 0.0f, 1.0f) * 255.0f + 0.5f);
+}
+PT_DEV unsigned displayTexel(float4 hdr, float exposure)
+{
+    const float r = hdr.x * exposure, g = hdr.y * exposure, b = hdr.z * exposure;
+    v3 c = mk3((r * 0.59719f + g * 0.35458f) + b * 0.04823f, (r * 0.07600f + g * 0.90834f) + b * 0.01566f,
+               (r * 0.02840f + g * 0.13383f) + b * 0.83777f);
+    const v3 num = c * (c + splat(0.0245786f)) - splat(0.000090537f);
+    const v3 den = c * (0.983729f * c + splat(0.4329510f)) + splat(0.238081f);
+    c = mk3(num.x / den.x, num.y / den.y, num.z / den.z);
+    const float x = (c.x * 1.60475f + c.y * -0.53108f) + c.z * -0.07367f;
+    const float y = (c.x * -0.10208f + c.y * 1.10813f) + c.z * -0.00605f;
+    const float z = (c.x * -0.00327f + c.y * -0.07276f) + c.z * 1.07602f;
+    return (unsigned)displayChannel(x) | ((unsigned)displayChannel(y) << 8) | ((unsigned)displayChannel(z) << 16);
+}
+// RGBA32F radiance image -> tightly packed RGB8.  Four texels per thread: three 4-byte stores.
+__global__ void displayKernel(const float4* __restrict__ in, unsigned char* __restrict__ out, size_t texels, float exposure)
+{
+    const size_t first = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (first >= texels) return;
+    if (first + 4 <= texels) {
+        const unsigned a = displayTexel(in[first], exposure), b = displayTexel(in[first + 1], exposure);
+        const unsigned c = displayTexel(in[first + 2], exposure), d = displayTexel(in[first + 3], exposure);
+        unsigned* o = reinterpret_cast<unsigned*>(out + first * 3);  // first * 3 is a multiple of 12
+        o[0] = a | (b << 24);
+        o[1] = (b >> 8) | (c << 16);
+        o[2] = (c >> 16) | (d << 8);
+    } else {
+        for (size_t i = first; i < texels; i++) {
+            const unsigned a = displayTexel(in[i], exposure);
+            out[i * 3] = (unsigned char)a;
+            out[i * 3 + 1] = (unsigned char)(a >> 8);
+            out[i * 3 + 2] = (unsigned char)(a >> 16);
+        }
+    }
+}
+
 // Element-wise evaluation of the float32 building blocks, so tests can compare them bit for bit
 // with a CPU evaluation of the same operation sequences.
 __global__ void evalMathKernel(int fn, const float* a, const float* b, float* out, size_t n)

@@ -184,9 +184,16 @@ int syncScene(pt_ctx* c)
         if (c->rebuildOnUpload) {
             // the uploaded tree was only validated; the device builder's tree over the same primitives is used
             std::vector<RefPrimitiveAlign> prims;
+            std::vector<RefNodeAlign> nodes;
             prims.swap(c->prims);  // buildLbvh drops the host copies
+            nodes.swap(c->nodes);
             const int rc = buildLbvh(c, prims.data(), prims.size());
-            return rc == PT_OK ? syncScene(c) : rc;
+            if (rc != PT_OK) {  // keep what the caller uploaded: the next dispatch fails the same way, not with "nothing uploaded"
+                c->prims.swap(prims);
+                c->nodes.swap(nodes);
+                return rc;
+            }
+            return syncScene(c);
         }
         if (packed.maxDepth > 64)
             return fail(PT_ERR_SCENE, "BVH is " + std::to_string(packed.maxDepth) + " interior levels deep; the traversal stack holds 64");
@@ -361,19 +368,11 @@ int wavefrontDispatch(pt_ctx* c, const DevParams& P, const DevScene& S, const Im
     return PT_OK;
 }
 
-int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t frameStride, bool counted, bool firstPart = true,
-                 bool lastPart = true)
+// The launch-constant block and the scene pointers of a dispatch, from the context's state.
+void fillLaunchBlocks(const pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t frameStride, DevParams& P, DevScene& S)
 {
-    if (!c) return fail(PT_ERR_INVALID, "null context");
-    if (frameCount == 0) return PT_OK;
-    if (frameFirst == 0) return fail(PT_ERR_INVALID, "FrameCount starts at 1 (weight 1/FrameCount)");
-    if (frameStride == 0) return fail(PT_ERR_INVALID, "frame_stride must be >= 1");
-    DeviceGuard guard(c->device);
-    int rc = syncScene(c);
-    if (rc != PT_OK) return rc;
-
     const pt_params& u = c->params;
-    DevParams P{};
+    P = DevParams{};
     Inverse4(u.view_matrix, P.invView);
     std::memcpy(P.invProj, u.inv_proj_matrix, 64);
     std::memcpy(P.view, u.view_matrix, 64);
@@ -404,7 +403,7 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
     P.tilesX = (uint32_t)((c->width + kMegaTile - 1) / kMegaTile);
     P.tilesY = (uint32_t)((c->height + kMegaTile - 1) / kMegaTile);
 
-    DevScene S{};
+    S = DevScene{};
     S.nodes = (const DevNode*)c->dNodes.ptr;
     S.triangles = (const DevTriangle*)c->dTriangles.ptr;
     S.shading = (const DevShading*)c->dShading.ptr;
@@ -419,6 +418,50 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
     P.refillMin = c->refillMin;
     P.hitMinNum = c->hitMinNum;
     P.waveTimes = nullptr;
+}
+
+// Launches the trace kernel variant that fits the tree in use.
+void launchTrace(const pt_ctx* c, const DevParams& P, const DevScene& S, const Images& img, DevCounters* ctr, dim3 grid, bool counted)
+{
+    const dim3 block(kMegaThreads);
+    // Trees up to 32 levels deep keep the whole traversal stack in LDS (8 KB per wave).  Deeper
+    // ones keep 32 entries there and the rest in private memory (3 % slower than the all-LDS kernel
+    // on a 5 M-triangle scene whose tree is 34 deep; a 40-entry LDS stack, 15 waves per CU, costs
+    // 6 %, a 48-entry one 13 %), or (deepStackInLds, for A/B) get a 12 or 16 KB LDS stack.
+    const int stackClass = c->maxDepth <= 32 ? 0 : (!c->deepStackInLds ? 3 : (c->maxDepth <= 48 ? 1 : 2));
+    // Three waves per SIMD (more registers, a quarter of the spills) for trees built by this library's
+    // own builders, four for uploaded ones: with few node visits per ray the shading blocks, where the
+    // spills are, weigh more (8.7 % faster at three on the benchmark scene's device-built tree, 0.8 %
+    // slower on the reference's tree of the same scene).
+    const bool three = c->wavesPerSimd == 3 || (c->wavesPerSimd == 0 && c->qualityTree);
+#define PT_LAUNCH_TRACE(COUNTED)                                                                                                 \
+    do {                                                                                                                         \
+        if (stackClass == 3 && three) hipLaunchKernelGGL((renderKernel<32, 32, COUNTED, 3>), grid, block, 0, c->stream, P, S, img, ctr); \
+        else if (stackClass == 3) hipLaunchKernelGGL((renderKernel<32, 32, COUNTED>), grid, block, 0, c->stream, P, S, img, ctr);        \
+        else if (stackClass == 2) hipLaunchKernelGGL((renderKernel<64, 0, COUNTED>), grid, block, 0, c->stream, P, S, img, ctr);         \
+        else if (stackClass == 1) hipLaunchKernelGGL((renderKernel<48, 0, COUNTED>), grid, block, 0, c->stream, P, S, img, ctr);         \
+        else if (three) hipLaunchKernelGGL((renderKernel<32, 0, COUNTED, 3>), grid, block, 0, c->stream, P, S, img, ctr);                \
+        else hipLaunchKernelGGL((renderKernel<32, 0, COUNTED>), grid, block, 0, c->stream, P, S, img, ctr);                              \
+    } while (0)
+    if (counted) PT_LAUNCH_TRACE(true);
+    else PT_LAUNCH_TRACE(false);
+#undef PT_LAUNCH_TRACE
+}
+
+int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t frameStride, bool counted, bool firstPart = true,
+                 bool lastPart = true)
+{
+    if (!c) return fail(PT_ERR_INVALID, "null context");
+    if (frameCount == 0) return PT_OK;
+    if (frameFirst == 0) return fail(PT_ERR_INVALID, "FrameCount starts at 1 (weight 1/FrameCount)");
+    if (frameStride == 0) return fail(PT_ERR_INVALID, "frame_stride must be >= 1");
+    DeviceGuard guard(c->device);
+    int rc = syncScene(c);
+    if (rc != PT_OK) return rc;
+
+    DevParams P;
+    DevScene S;
+    fillLaunchBlocks(c, frameFirst, frameCount, frameStride, P, S);
     if (firstPart) HIP_TRY(hipMemsetAsync(c->dCounters.ptr, 0, sizeof(DevCounters), c->stream));
     DevCounters* ctr = (DevCounters*)c->dCounters.ptr;
     Images img{imagePtr(c, 0), imagePtr(c, 1), imagePtr(c, 2)};
@@ -498,30 +541,9 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
             HIP_TRY(hipMemsetAsync(c->dWaveTimes.ptr, 0, c->waveTimeCount * 16, c->stream));
             P.waveTimes = (unsigned long long*)c->dWaveTimes.ptr;
         }
-        const dim3 grid((unsigned)gridBlocks), block(kMegaThreads);
+        const dim3 grid((unsigned)gridBlocks);
         HIP_TRY(hipEventRecord(c->evTrace0, c->stream));
-        // Trees up to 32 levels deep keep the whole traversal stack in LDS (8 KB per wave).  Deeper
-        // ones keep 32 entries there and the rest in private memory (3 % slower than the all-LDS kernel
-        // on a 5 M-triangle scene whose tree is 34 deep; a 40-entry LDS stack, 15 waves per CU, costs
-        // 6 %, a 48-entry one 13 %), or (deepStackInLds, for A/B) get a 12 or 16 KB LDS stack.
-        const int stackClass = c->maxDepth <= 32 ? 0 : (!c->deepStackInLds ? 3 : (c->maxDepth <= 48 ? 1 : 2));
-        // Three waves per SIMD (more registers, a quarter of the spills) for trees built by this library's
-        // own builders, four for uploaded ones: with few node visits per ray the shading blocks, where the
-        // spills are, weigh more (8.7 % faster at three on the benchmark scene's device-built tree, 0.8 %
-        // slower on the reference's tree of the same scene).
-        const bool three = c->wavesPerSimd == 3 || (c->wavesPerSimd == 0 && c->qualityTree);
-#define PT_LAUNCH_TRACE(COUNTED)                                                                                         \
-    do {                                                                                                                 \
-        if (stackClass == 3 && three) hipLaunchKernelGGL((renderKernel<32, 32, COUNTED, 3>), grid, block, 0, c->stream, P, S, img, ctr); \
-        else if (stackClass == 3) hipLaunchKernelGGL((renderKernel<32, 32, COUNTED>), grid, block, 0, c->stream, P, S, img, ctr); \
-        else if (stackClass == 2) hipLaunchKernelGGL((renderKernel<64, 0, COUNTED>), grid, block, 0, c->stream, P, S, img, ctr); \
-        else if (stackClass == 1) hipLaunchKernelGGL((renderKernel<48, 0, COUNTED>), grid, block, 0, c->stream, P, S, img, ctr); \
-        else if (three) hipLaunchKernelGGL((renderKernel<32, 0, COUNTED, 3>), grid, block, 0, c->stream, P, S, img, ctr);        \
-        else hipLaunchKernelGGL((renderKernel<32, 0, COUNTED>), grid, block, 0, c->stream, P, S, img, ctr);                      \
-    } while (0)
-        if (counted) PT_LAUNCH_TRACE(true);
-        else PT_LAUNCH_TRACE(false);
-#undef PT_LAUNCH_TRACE
+        launchTrace(c, P, S, img, ctr, grid, counted);
         HIP_TRY(hipEventRecord(c->evTrace1, c->stream));
         hipLaunchKernelGGL(resolveKernel, dim3((unsigned)((P.pixels + 255) / 256)), dim3(256), 0, c->stream, P, img);
         HIP_TRY(hipGetLastError());
@@ -682,6 +704,8 @@ int pt_upload_primitives(pt_ctx* c, const void* prims112, size_t count)
     c->prims.assign(p, p + count);
     c->geometryDirty = true;
     c->deviceGeometry = false;
+    c->qualityTree = false;
+    c->tileCostValid = false;
     return PT_OK;
 }
 
@@ -816,8 +840,9 @@ int processBuffers(pt_ctx* c, bool uncapped)
     if (rc != PT_OK) return rc;
     rc = pt_upload_nodes(c, nodesAligned.data(), nodesAligned.size());
     if (rc != PT_OK) return rc;
-    c->qualityTree = uncapped;
-    return pt_upload_primitives(c, primsAligned.data(), primsAligned.size());
+    rc = pt_upload_primitives(c, primsAligned.data(), primsAligned.size());
+    c->qualityTree = rc == PT_OK && uncapped;
+    return rc;
 }
 
 int buildBvhSah(void* prims100, size_t count, int leafSize, void* nodes40Out, size_t nodeCapacity, size_t* nodeCountOut,
@@ -1108,6 +1133,21 @@ int pt_read_image_rgb(pt_ctx* c, int which, float* rgbOut)
     return PT_OK;
 }
 
+int pt_read_display(pt_ctx* c, float exposure, unsigned char* rgb8Out)
+{
+    if (!c || !rgb8Out) return fail(PT_ERR_INVALID, "null argument");
+    DeviceGuard guard(c->device);
+    const size_t texels = (size_t)c->width * c->height;
+    HIP_TRY(c->dRgbStaging.ensure(texels * 3 * sizeof(float)));  // shared with pt_read_image_rgb
+    const size_t quads = (texels + 3) / 4;
+    hipLaunchKernelGGL(displayKernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, c->stream, imagePtr(c, PT_IMAGE_RADIANCE),
+                       (unsigned char*)c->dRgbStaging.ptr, texels, exposure);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rgb8Out, c->dRgbStaging.ptr, texels * 3, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
 int pt_get_stats(pt_ctx* c, pt_stats* out)
 {
     if (!c || !out) return fail(PT_ERR_INVALID, "null argument");
@@ -1387,6 +1427,14 @@ int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count)
     if (count == 0) return fail(PT_ERR_INVALID, "no primitives");
     if (count >= (1u << 27)) return fail(PT_ERR_INVALID, "too many primitives (limit 2^27)");
     DeviceGuard guard(c->device);
+    // The build writes into the live geometry buffers and can still fail after that: from here until it
+    // succeeds the context has no geometry (a dispatch returns PT_ERR_STATE, never an old tree over new
+    // triangles).
+    c->deviceGeometry = false;
+    c->geometryDirty = true;
+    c->tileCostValid = false;
+    c->nodes.clear();
+    c->prims.clear();
     const int n = (int)count;
     const unsigned int un = (unsigned int)count;
     const size_t internal = count > 1 ? count - 1 : 1;

@@ -191,6 +191,13 @@ class Renderer:
         check(self._lib.pt_read_image_rgb(self._h, int(which), _ptr(out)))
         return out
 
+    def read_display(self, exposure=1.0):
+        """(height, width, 3) uint8: the radiance image through the reference's display pass
+        (exposure, ACES fit, sRGB encoding), row 0 = bottom row."""
+        out = np.empty((self.height, self.width, 3), np.uint8)
+        check(self._lib.pt_read_display(self._h, float(exposure), _ptr(out)))
+        return out
+
     def stats(self):
         s = Stats()
         check(self._lib.pt_get_stats(self._h, ctypes.byref(s)))

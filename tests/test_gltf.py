@@ -173,6 +173,36 @@ def test_generated_normals_and_errors(tmp_path):
         gltf.load(_write_gltf(tmp_path, doc, blob, name="overrun"))
 
 
+def test_hostile_offsets_and_counts_are_refused(tmp_path):
+    """Numbers from the file that would wrap the range check: negative offsets (a huge size_t after the
+    cast) and counts whose product with the stride overflows."""
+    def refuse(mutate, name, match="past|negative|outside"):
+        doc, blob, _ = _quad_document(stride=16)
+        mutate(doc)
+        with pytest.raises(PtError, match=match) as e:
+            gltf.load(_write_gltf(tmp_path, doc, blob, name=name))
+        assert e.value.code == -5
+
+    def negative_accessor_offset(doc):  # with count 2 and stride 16 the wrapped end lands inside the view
+        doc["accessors"][0].update(byteOffset=-16, count=2)
+    refuse(negative_accessor_offset, "negoff")
+    refuse(lambda d: d["bufferViews"][0].update(byteOffset=-16), "negview")
+    refuse(lambda d: d["bufferViews"][0].update(byteLength=-1), "neglen")
+    refuse(lambda d: d["bufferViews"][0].update(byteStride=-16), "negstride")
+    refuse(lambda d: d["accessors"][0].update(count=-4), "negcount")
+    refuse(lambda d: d["accessors"][0].update(count=2 ** 60 + 1), "hugecount")  # (count - 1) * 16 wraps to 0
+    refuse(lambda d: d["accessors"][3].update(count=2 ** 63 - 1), "hugeindices")
+    refuse(lambda d: d["accessors"][0].update(byteOffset=2 ** 62), "hugeoff")
+    refuse(lambda d: d["bufferViews"][0].update(byteLength=2 ** 62), "hugelen")
+    # an embedded image whose view lies outside the buffer, by a negative offset or a wrapping length
+    for k, view in enumerate(({"buffer": 0, "byteOffset": -8, "byteLength": 8}, {"buffer": 0, "byteOffset": 8, "byteLength": 2 ** 64 - 4},
+                              {"buffer": 0, "byteOffset": 2 ** 40, "byteLength": 4})):
+        doc, blob, _ = _quad_document(images=[{"bufferView": 4, "mimeType": "image/png"}], textures=[{"source": 0}])
+        doc["bufferViews"].append(view)
+        with pytest.raises(PtError, match="outside"):
+            gltf.load(_write_glb(tmp_path, doc, blob, name=f"img{k}"))
+
+
 def test_textures_slots_and_flip(tmp_path):
     from PIL import Image
     rgb = np.zeros((2, 3, 3), np.uint8)

@@ -106,6 +106,63 @@ def test_process_buffers_device_and_errors():
     assert e.value.code == -5
 
 
+def _morton_chain_soup():
+    """Tiny triangles whose centroids quantise to Morton codes with one bit set each (63 of them), plus the
+    all-ones corner and a pile at the origin: the Morton radix tree over them is a chain more than 64 levels
+    deep, which the device builder refuses (PT_ERR_SCENE)."""
+    pts = [(2097151.0, 2097151.0, 2097151.0)] + [(0.0, 0.0, 0.0)] * 40
+    for j in range(21):
+        c = float(2 ** j) + 0.5
+        pts += [(c, 0.0, 0.0), (0.0, c, 0.0), (0.0, 0.0, c)]
+    e = 0.01
+    v, idx = [], []
+    for k, (x, y, z) in enumerate(pts):
+        v += [[x, y, z, 0, 0, 1, 0, 0], [x + e, y, z, 0, 0, 1, 1, 0], [x, y + e, z, 0, 0, 1, 0, 1]]
+        idx += [3 * k, 3 * k + 1, 3 * k + 2]
+    return np.array(v, np.float32), np.array(idx, np.uint32)
+
+
+def test_failed_device_build_leaves_no_stale_geometry():
+    """A device build that fails after it has started writing must not leave the previous tree in place
+    over new triangles: the next dispatch reports an error until a build succeeds."""
+    meshes, mats = scenes.flatten(scenes.recipe("TorusMixed"))
+    hdri, cache = environment(256, 128)
+    g = R.Renderer(64, 64)
+    for (v, i), m in zip(meshes, mats):
+        g.AddPathTracingModel(v, i, m)
+    g.ProcessBuffersDevice()
+    g.upload_environment(hdri, cache)
+    g.set_params(R.default_params(64, 64))
+    g.clear()
+    g.dispatch(1, 1, 1)  # a good scene is live
+    cv, ci = _morton_chain_soup()
+    chain = R.align_primitives(R.assemble_primitives(cv, ci, 0))
+    g.set_tuning(ploc_radius=0)  # the Morton radix tree: its depth follows the key bits
+    with pytest.raises(PtError, match="levels deep") as e:
+        g.build_bvh_device(chain)
+    assert e.value.code == -5
+    with pytest.raises(PtError) as e:  # no geometry now: neither the old tree nor a half-built one
+        g.dispatch(2, 1, 1)
+    assert e.value.code == -2
+    with pytest.raises(PtError):
+        g.download_bvh()
+    # the rebuild-on-upload path: the uploaded tree is valid, the device build over its primitives fails;
+    # every dispatch says so, and the uploaded buffers survive for a later, successful build
+    sorted_prims, nodes40 = R.build_bvh_sah(R.assemble_primitives(cv, ci, 0), 4)
+    g.set_bvh_rebuild(True)
+    g.upload_nodes(R.align_nodes(nodes40))
+    g.upload_primitives(R.align_primitives(sorted_prims))
+    for frame in (2, 3):
+        with pytest.raises(PtError, match="levels deep") as e:
+            g.dispatch(frame, 1, 1)
+        assert e.value.code == -5
+    g.set_tuning(ploc_radius=32)  # the clustering builder copes with the same soup
+    g.dispatch(2, 1, 1)
+    nodes, prims = g.download_bvh()
+    _check_tree(nodes, prims, chain)
+    assert np.isfinite(g.read_image(0)).all()
+
+
 def test_full_sweep_tree_renders_like_the_oracle_and_like_the_reference_tree():
     """The sweep builder without the reference's cost cap gives another tree over the same triangles:
     the GPU image equals the oracle's on that tree bit for bit, and equals the image traced through

@@ -90,4 +90,9 @@ def test_cpp_host_renders_the_same_image(tmp_path, device_bvh):
     py = g.read_image_rgb(0)
     assert cpp.shape == py.shape
     assert np.array_equal(np.ascontiguousarray(cpp).view(np.uint32), py.view(np.uint32))
-    assert os.path.getsize(tmp_path / "cpp.ppm") == len(f"P6\n{width} {height}\n255\n") + width * height * 3
+    # the display image the C++ host wrote (pt_read_display, rows top to bottom in the file)
+    header = f"P6\n{width} {height}\n255\n".encode()
+    blob = open(tmp_path / "cpp.ppm", "rb").read()
+    assert blob[:len(header)] == header and len(blob) == len(header) + width * height * 3
+    ppm = np.frombuffer(blob, np.uint8, offset=len(header)).reshape(height, width, 3)[::-1]
+    assert np.array_equal(ppm, g.read_display(1.0))

@@ -413,6 +413,32 @@ def test_read_image_rgb_is_the_rgba_image_without_alpha():
             assert np.array_equal(rgb.view(np.uint32), rgba[..., :3].view(np.uint32).reshape(height, width, 3))
 
 
+def test_read_display_is_the_display_pass_of_the_radiance_image():
+    """pt_read_display (tone mapping + sRGB encoding on the device) against the oracle's restatement of
+    tonemapping.frag:36-71 applied to the same radiance image.  Tolerance: 0 of 255 -- both sides run the
+    same float32 operation sequence, pow included (it is built from pinned polynomials on both sides)."""
+    for width, height in ((37, 29), (128, 64)):  # 1073 texels: the kernel's tail path runs too
+        o, g = _pair("TorusMixed", width, height)
+        g.set_params(R.default_params(width, height))
+        g.clear()
+        g.dispatch(1, 4, 1)
+        hdr = g.read_image(0)
+        for exposure in (1.0, 0.2, 6.0):
+            got = g.read_display(exposure)
+            assert got.shape == (height, width, 3) and got.dtype == np.uint8
+            assert np.array_equal(got, ob.display(hdr, exposure))
+        assert 0 < g.read_display(1.0).mean() < 255
+    # synthetic radiance through pt_write_image: zeros, huge values, tiny values, a NaN-free ramp
+    g = R.Renderer(64, 16)
+    ramp = np.zeros((16, 64, 4), np.float32)
+    ramp[..., 0] = np.geomspace(1e-6, 1e4, 64, dtype=np.float32)[None, :]
+    ramp[..., 1] = np.linspace(0.0, 2.0, 16, dtype=np.float32)[:, None]
+    ramp[..., 2] = 1e30
+    ramp[0, 0] = 0.0
+    g.write_image(0, ramp)
+    assert np.array_equal(g.read_display(1.0), ob.display(ramp, 1.0))
+
+
 def test_error_behaviour():
     g = R.Renderer(32, 32)
     with pytest.raises(L.PtError) as e:

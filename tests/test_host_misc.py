@@ -40,6 +40,24 @@ def test_hdri_cache_matches_oracle_bitwise():
         assert abs(float(ours[..., 2].astype(np.float64).sum()) - 1.0) < 1e-3
 
 
+@pytest.mark.skipif(ob.ref_hdri_lib() is None, reason="oracle/_ref/libref_hdri.so not built (reference absent)")
+def test_hdri_cache_matches_the_reference_code_bitwise():
+    """pt_calculate_hdri_cache and the oracle's restatement against the reference's own statements
+    (PathTracingRenderer.cpp:803-901 compiled in place): every float of the cache, bit for bit."""
+    rng = np.random.default_rng(7)
+    cases = [scenes.sky_hdri(w, h) for (w, h) in [(64, 32), (256, 128), (37, 19), (1024, 512)]]
+    cases.append(rng.uniform(0.0, 4.0, (48, 96, 3)).astype(np.float32))          # noise
+    spiky = rng.uniform(0.0, 0.01, (33, 70, 3)).astype(np.float32)               # a few very bright texels
+    spiky[5, 7] = 5000.0
+    spiky[20, 60] = (900.0, 0.0, 30.0)
+    cases.append(spiky)
+    cases.append(np.full((16, 16, 3), 0.25, np.float32))                          # constant: every CDF step equal
+    for hdri in cases:
+        want = ob.ref_calculate_hdri_cache(hdri)
+        assert R.calculate_hdri_cache(hdri).tobytes() == want.tobytes(), hdri.shape
+        assert ob.calculate_hdri_cache(hdri).tobytes() == want.tobytes(), hdri.shape
+
+
 def test_hdri_cache_follows_the_sun():
     hdri = scenes.sky_hdri(128, 64)
     cache = R.calculate_hdri_cache(hdri)

@@ -23,6 +23,24 @@ def test_tonemap_matches_shader_formula_and_is_monotone():
     assert np.allclose(enc, np.where(want <= 0.0031308, want * 12.92, 1.055 * want ** (1 / 2.4) - 0.055), atol=1e-5)
 
 
+def test_oracle_display_pass_agrees_with_the_numpy_transform():
+    """The oracle's restatement of the display pass (tonemapping.frag:36-71 + sRGB encoding + 8-bit
+    conversion, built on its fixed-polynomial pow) against the NumPy transform of image_io, whose pow is
+    libm's: at most 1 of 255 apart, almost always equal."""
+    from oracle import binding as ob
+    rng = np.random.default_rng(3)
+    hdr = np.concatenate([rng.uniform(0, 4, (64, 64, 4)), rng.uniform(0, 0.02, (64, 64, 4)), rng.uniform(0, 300, (64, 64, 4))]).astype(np.float32)
+    hdr[0, 0] = 0.0
+    hdr[0, 1] = (1e15, 0.0, 1e-30, 1.0)
+    for exposure in (1.0, 0.25, 3.0):
+        got = ob.display(hdr, exposure).astype(np.int32)
+        want = (np.clip(image_io.tonemap(hdr[..., :3], exposure), 0.0, 1.0) * 255.0 + 0.5).astype(np.int32)
+        assert np.abs(got - want).max() <= 1
+        assert (got != want).mean() < 1e-3
+    assert tuple(ob.display(np.zeros((1, 1, 4), np.float32))[0, 0]) == (0, 0, 0)
+    assert tuple(ob.display(np.full((1, 1, 4), 1e6, np.float32))[0, 0]) == (255, 255, 255)
+
+
 def test_png_roundtrip(tmp_path):
     from PIL import Image
     rng = np.random.default_rng(0)
