@@ -139,3 +139,116 @@ def test_three_builders_one_image():
         for a, b in zip(images[0], other):
             differing = int(np.any(a.view(np.uint32) != b.view(np.uint32), axis=-1).sum())
             assert differing <= 1e-4 * 200 * 120, differing
+
+
+def _interior():
+    from pathtracer_amd import recipes
+    meshes, mats, textures, _ = recipes.load_scene("Interior")
+    tex = {slot: (texels, srgb) for slot, texels, srgb in textures}
+    return built_meshes(meshes, mats), tex, recipes.INTERIOR_CAMERA
+
+
+@PIPELINES
+def test_interior_stand_in_bit_exact(pipeline):
+    """The stand-in for the reference's Fireplace scene (closed textured room, one window, emissive
+    panel, transmissive solids): 160 x 120 x 2 spp, 8 bounces, bit-exact against the oracle."""
+    scene, tex, cam = _interior()
+    gpu, st = _render_both(scene, tex, 160, 120, cam["eye"], cam["look_at"], 8, 2, pipeline, "interior 160x120 2spp")
+    assert st.rays_any > 0 and gpu[1][..., :3].std() > 0.02  # shadow rays were traced, the textures show
+    # a closed room seen from inside: nearly every primary ray hits a surface and leaves a primary normal
+    # (the exceptions look out of the window, or end at their first bounce)
+    n = gpu[2][..., :3].astype(np.float64)
+    assert ((n * n).sum(-1) > 0.25).mean() > 0.5
+
+
+def test_interior_full_hd_properties():
+    """The interior at the benchmark's 1920 x 1080, checked through properties the oracle does not have
+    to render in full: one 8-frame dispatch equals eight one-frame dispatches bit for bit, two disjoint
+    FrameCount shards in sum mode add up to their union (the multi-GPU identity), and three 8-row bands
+    equal the oracle."""
+    scene, tex, cam = _interior()
+    width, height = 1920, 1080
+    o, g = _pair(scene, width, height, textures=tex)
+    p = R.default_params(width, height)
+    p.max_bounces = 8
+    R.set_camera(p, cam["eye"], cam["look_at"], width, height)
+    g.set_params(p)
+    g.clear()
+    g.dispatch(1, 8, 1)
+    whole = [g.read_image(k) for k in range(3)]
+    g.clear()
+    for f in range(1, 9):
+        g.dispatch(f, 1, 1)
+    for k in range(3):
+        assert g.read_image(k).tobytes() == whole[k].tobytes()
+    g.clear()
+    g.dispatch(1, 2, 1)
+    gpu = [g.read_image(k) for k in range(3)]
+    for y0, y1 in ((0, 8), (536, 544), (1072, 1080)):
+        cpu = o.render(p, width, height, 1, 2, 1, rows=(y0, y1))
+        assert cpu[4].stack_overflows == 0
+        for k in range(3):
+            assert gpu[k][y0:y1].tobytes() == cpu[k][y0:y1].tobytes(), (y0, k)
+    p.accumulate_mode = 1
+    g.set_params(p)
+    parts = []
+    for rank in range(2):
+        g.clear()
+        g.dispatch(1 + rank, 4, 2)
+        parts.append(g.read_image(0).astype(np.float64))
+    g.clear()
+    g.dispatch(1, 8, 1)
+    union = g.read_image(0).astype(np.float64)
+    assert np.all(union[..., 3] == 8.0)
+    assert np.all(np.abs(parts[0] + parts[1] - union) <= 1e-5 * np.maximum(1.0, np.abs(union)))
+
+
+def test_twenty_million_triangles_uhd():
+    """The largest benchmark configuration at full size: 139 bunnies flattened on a grid (20 M triangles,
+    a 3 GB scene that no cache holds), tree built on the GPU, 3840 x 2160.  Two frames in one dispatch
+    equal two one-frame dispatches bit for bit, and three 4-row bands equal the oracle traversing the
+    downloaded tree."""
+    from oracle import binding as ob
+    meshes, mats, side = scenes.instanced_bunnies(139)
+    soup112 = R.align_primitives(np.concatenate([R.assemble_primitives(v, i, k) for k, (v, i) in enumerate(meshes)]))
+    assert soup112.shape[0] > 20_000_000
+    del meshes
+    width, height = 3840, 2160
+    g = R.Renderer(width, height)
+    g.build_bvh_device(soup112)
+    del soup112
+    g.upload_materials(mats)
+    hdri, cache = environment(256, 128)
+    g.upload_environment(hdri, cache)
+    p = R.default_params(width, height)
+    p.max_bounces = 8
+    R.set_camera(p, (-2.5 - 1.1 * side, 1.0 + 0.8 * side, 0.0), (0.0, 0.0, 0.0), width, height)
+    g.set_params(p)
+    g.clear()
+    g.dispatch(1, 2, 1, counted=True)
+    st = g.stats()
+    whole = [g.read_image(k) for k in range(3)]
+    assert st.samples == 2 * width * height and 0 < st.max_stack_depth <= 64
+    print(f"20 M triangles: max traversal-stack occupancy {st.max_stack_depth}, "
+          f"{st.node_visits / (st.rays_closest + st.rays_any):.1f} node visits per ray")
+    g.clear()
+    g.dispatch(1, 1, 1)
+    g.dispatch(2, 1, 1)
+    for k in range(3):
+        assert g.read_image(k).tobytes() == whole[k].tobytes()
+    nodes, prims = g.download_bvh()
+    o = ob.Oracle()
+    o.set_scene(nodes, prims, mats)
+    o.set_environment(hdri, cache)
+    for y0, y1 in ((300, 304), (1078, 1082), (1900, 1904)):
+        cpu = o.render(p, width, height, 1, 2, 1, rows=(y0, y1))
+        for k in range(3):
+            bad = _diff_rows(whole[k][y0:y1], cpu[k][y0:y1], cpu[3][y0:y1])
+            assert bad == 0, (y0, k, bad)
+
+
+def _diff_rows(a, b, overflow_mask):
+    """Differing pixels of two row bands, not counting pixels where the oracle's 16-entry traversal stack
+    overflowed (the shader's behaviour there is undefined; the kernel's stack cannot overflow)."""
+    ne = np.any(a.view(np.uint32) != b.view(np.uint32), axis=-1)
+    return int((ne & (overflow_mask == 0)).sum())
