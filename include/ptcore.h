@@ -90,7 +90,7 @@ typedef struct pt_params {
 } pt_params;
 
 /* Counters of the most recent dispatch.  samples, rays_closest, rays_any and closest_hits are kept by
- * every dispatch (pt_dispatch, pt_dispatch_counted); node_visits, triangle_tests and
+ * every dispatch (pt_dispatch, pt_dispatch_static, pt_dispatch_counted); node_visits, triangle_tests and
  * max_stack_depth only by pt_dispatch_counted() and are zero after the others. */
 typedef struct pt_stats {
     uint64_t samples;         /* (pixel, FrameCount) pairs traced                        */
@@ -274,6 +274,17 @@ int pt_clear(pt_ctx* ctx);
 int pt_dispatch(pt_ctx* ctx, uint32_t frame_first, uint32_t frame_count, uint32_t frame_stride);
 /* Same image result, and additionally fills the pt_stats counters (slower). */
 int pt_dispatch_counted(pt_ctx* ctx, uint32_t frame_first, uint32_t frame_count, uint32_t frame_stride);
+/* No counterpart in the reference.  pt_dispatch for callers that cannot allocate device memory: code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernels and
+ * bit-identical images, but nothing is allocated, freed, uploaded or timed: the sample records of the
+ * launch and the per-tile cost words live in a static device array of PT_STATIC_SCRATCH_BYTES that every
+ * GPU the library runs on holds until the process ends, and tiles launch in row-major order (no launch
+ * plan).  PT_ERR_INVALID when 256 + 48 bytes x width x height x frame_count (+ 4 per 8x8 tile) exceed the
+ * array: dispatch fewer frames per call.  PT_ERR_STATE when scene buffers or textures changed since the
+ * last pt_dispatch (which uploads them), or under the wavefront scheduler.  All contexts on one GPU share
+ * the array: calls that overlap on one GPU (different streams or threads) race. */
+#define PT_STATIC_SCRATCH_BYTES (128u << 20)
+int pt_dispatch_static(pt_ctx* ctx, uint32_t frame_first, uint32_t frame_count, uint32_t frame_stride);
 /* Multiply the three images by `scale` (sum mode: 1/N after the cross-GPU reduce). */
 int pt_scale_images(pt_ctx* ctx, float scale);
 int pt_synchronize(pt_ctx* ctx);

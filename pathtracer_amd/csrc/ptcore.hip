@@ -75,7 +75,17 @@ struct PendingModel {
     RefMaterialAlign material;
 };
 
+// Scratch of pt_dispatch_static: the one entry point that allocates nothing.  Every GPU the library
+// runs on holds its own copy of the array, at its own address, until the process ends; host code
+// reaches it only through the per-device pointer taken once in pt_create (the array's name is a
+// host-side stand-in, not a device address).
+constexpr size_t kStaticScratchBytes = PT_STATIC_SCRATCH_BYTES;
+constexpr int kMaxDevices = 64;
+void* g_scratchPtr[kMaxDevices] = {};
+
 }  // namespace
+
+static __device__ __align__(256) unsigned char scratch[PT_STATIC_SCRATCH_BYTES];
 
 struct pt_ctx {
     int device = 0;
@@ -603,6 +613,12 @@ int pt_create(int device, int width, int height, pt_ctx** out)
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(PT_ERR_DEVICE, std::string("kernels are built for gfx950 only; device is ") + prop.gcnArchName);
     DeviceGuard guard(device);
+    if (device >= kMaxDevices) return fail(PT_ERR_INVALID, "device index above 63");
+    if (!g_scratchPtr[device]) {  // once per device, with that device current
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        g_scratchPtr[device] = p;
+    }
     std::unique_ptr<pt_ctx> c(new (std::nothrow) pt_ctx());
     if (!c) return fail(PT_ERR_NOMEM, "out of host memory");
     c->device = device;
@@ -1074,6 +1090,53 @@ int pt_dispatch(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t fr
 int pt_dispatch_counted(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t frameStride)
 {
     return dispatchSplit(c, frameFirst, frameCount, frameStride, true);
+}
+
+// pt_dispatch for callers that cannot allocate.  Same kernels, same images; the sample records and
+// the per-tile cost words live in the static scratch array of the context's GPU instead of buffers
+// the context would (re)allocate, tiles are launched in row-major order (the launch plan needs sort
+// scratch), nothing is uploaded and no event is recorded.
+int pt_dispatch_static(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t frameStride)
+{
+    if (!c) return fail(PT_ERR_INVALID, "null context");
+    if (frameCount == 0) return PT_OK;
+    if (frameFirst == 0) return fail(PT_ERR_INVALID, "FrameCount starts at 1 (weight 1/FrameCount)");
+    if (frameStride == 0) return fail(PT_ERR_INVALID, "frame_stride must be >= 1");
+    if (frameCount > 65535u) return fail(PT_ERR_INVALID, "a megakernel launch takes at most 65535 frames");
+    if (c->pipeline != 0) return fail(PT_ERR_STATE, "pt_dispatch_static runs the megakernel scheduler only");
+    if (!c->haveParams) return fail(PT_ERR_STATE, "pt_set_params has not been called");
+    if (c->geometryDirty || c->materialsDirty || c->texturesDirty || c->envDirty)
+        return fail(PT_ERR_STATE, "scene buffers changed since the last pt_dispatch: this entry point uploads nothing, "
+                                  "run one pt_dispatch first");
+    unsigned char* base = (unsigned char*)g_scratchPtr[c->device];
+    if (!base) return fail(PT_ERR_STATE, "no static scratch on this device");
+    const size_t pixels = (size_t)c->width * c->height;
+    const size_t tiles = (size_t)((c->width + kMegaTile - 1) / kMegaTile) * (size_t)((c->height + kMegaTile - 1) / kMegaTile);
+    const size_t costBytes = (tiles * 4 + 255) / 256 * 256;
+    const size_t need = costBytes + (size_t)frameCount * pixels * 48u;
+    if (need > kStaticScratchBytes)
+        return fail(PT_ERR_INVALID, "pt_dispatch_static: " + std::to_string(frameCount) + " frames of " + std::to_string(c->width) + "x" +
+                                        std::to_string(c->height) + " need " + std::to_string(need) + " bytes of scratch, the static array holds " +
+                                        std::to_string(kStaticScratchBytes) + " (dispatch fewer frames per call)");
+    DeviceGuard guard(c->device);
+    DevParams P;
+    DevScene S;
+    fillLaunchBlocks(c, frameFirst, frameCount, frameStride, P, S);
+    P.tileCost = (unsigned int*)base;
+    P.samples = (float*)(base + costBytes);
+    P.pixels = pixels;
+    P.blockList = nullptr;
+    P.blockCount = nullptr;
+    DevCounters* ctr = (DevCounters*)c->dCounters.ptr;  // allocated by pt_create
+    Images img{imagePtr(c, 0), imagePtr(c, 1), imagePtr(c, 2)};
+    HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(DevCounters), c->stream));
+    HIP_TRY(hipMemsetAsync(base, 0, costBytes, c->stream));  // the array keeps the previous call's contents
+    launchTrace(c, P, S, img, ctr, dim3((unsigned)tiles), false);
+    hipLaunchKernelGGL(resolveKernel, dim3((unsigned)((P.pixels + 255) / 256)), dim3(256), 0, c->stream, P, img);
+    HIP_TRY(hipGetLastError());
+    c->timed = false;  // no events around this launch
+    c->kernelTimed = false;
+    return PT_OK;
 }
 
 int pt_scale_images(pt_ctx* c, float scale)

@@ -130,6 +130,10 @@ class Renderer:
         fn = self._lib.pt_dispatch_counted if counted else self._lib.pt_dispatch
         check(fn(self._h, int(frame_first), int(frame_count), int(frame_stride)))
 
+    def dispatch_static(self, frame_first, frame_count=1, frame_stride=1):
+        """pt_dispatch_static: the dispatch that allocates nothing (scratch in a static device array)."""
+        check(self._lib.pt_dispatch_static(self._h, int(frame_first), int(frame_count), int(frame_stride)))
+
     TUNING_KEYS = {"pipeline": 0, "trav_exit": 1, "refill_min": 2, "check_every": 3, "traverse_blocks": 4, "hit_min": 5, "tile_order": 6, "tile_split": 7, "sample_budget_mib": 8, "deep_stack_in_lds": 9, "ploc_radius": 10, "waves_per_simd": 11}
 
     def set_tuning(self, **kw):
