@@ -126,11 +126,16 @@ PT_DEV void stackPut(int* stack, int* deep, int i, int v)
     if (LDS_DEPTH == 0 || i < LDS_DEPTH) stack[i * STRIDE] = v;
     else deep[i - LDS_DEPTH] = v;
 }
+// (With a private part, the LDS load is unconditional and the private one sits in a branch of its own
+// behind it, volatile so that it stays there: given one plain load in each arm of a branch the compiler
+// merges them into a single access through a selected generic pointer, a flat load slower than either.)
 template <int STRIDE, int LDS_DEPTH>
 PT_DEV int stackGet(const int* stack, const int* deep, int i)
 {
-    if (LDS_DEPTH == 0 || i < LDS_DEPTH) return stack[i * STRIDE];
-    return deep[i - LDS_DEPTH];
+    if (LDS_DEPTH == 0) return stack[i * STRIDE];
+    int v = stack[(i < LDS_DEPTH ? i : LDS_DEPTH - 1) * STRIDE];
+    if (i >= LDS_DEPTH) v = const_cast<const volatile int*>(deep)[i - LDS_DEPTH];
+    return v;
 }
 
 template <bool COUNT, int STRIDE = kBlockThreads, int LDS_DEPTH = 0>

@@ -75,19 +75,32 @@ PT_DEV float bilerp(const Bilerp& q, float t00, float t10, float t01, float t11)
 
 PT_DEV float4 fetchTexel(const DevScene& S, const DevTexture& t, int x, int y)
 {
-    float o[4] = {0.0f, 0.0f, 0.0f, 1.0f};
-    size_t idx = ((size_t)y * (size_t)t.width + (size_t)x) * (size_t)t.channels;
+    // (four scalars, not an array: an array indexed by the channel loop lives in scratch memory)
+    float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 1.0f;
+    const size_t idx = ((size_t)y * (size_t)t.width + (size_t)x) * (size_t)t.channels;
+    const int n = t.channels;  // 1..4
     if (t.format == 2) {
         const float* p = (const float*)(S.texels + t.offset) + idx;
-        for (int c = 0; c < t.channels; c++) o[c] = p[c];
+        o0 = p[0];
+        if (n > 1) o1 = p[1];
+        if (n > 2) o2 = p[2];
+        if (n > 3) o3 = p[3];
     } else {
         const unsigned char* p = S.texels + t.offset + idx;
-        for (int c = 0; c < t.channels; c++) {
-            unsigned char b = p[c];
-            o[c] = (t.format == 1 && c < 3) ? S.srgbLut[b] : (float)b / 255.0f;
+        const bool srgb = t.format == 1;
+        const unsigned b0 = p[0];
+        o0 = srgb ? S.srgbLut[b0] : (float)b0 / 255.0f;
+        if (n > 1) {
+            const unsigned b = p[1];
+            o1 = srgb ? S.srgbLut[b] : (float)b / 255.0f;
         }
+        if (n > 2) {
+            const unsigned b = p[2];
+            o2 = srgb ? S.srgbLut[b] : (float)b / 255.0f;
+        }
+        if (n > 3) o3 = (float)p[3] / 255.0f;  // alpha stays linear
     }
-    return make_float4(o[0], o[1], o[2], o[3]);
+    return make_float4(o0, o1, o2, o3);
 }
 PT_DEV float4 sampleTexture(const DevScene& S, int texIndex, float u, float v)
 {
