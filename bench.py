@@ -291,9 +291,6 @@ def main():
         work = build_workload(args)
         sr = ShardedRenderer(W, H, local_rank, rank, world)
         g = sr.renderer
-        if args.bvh == "full-sweep" and "waves_per_simd" not in args.tuning:
-            # an uploaded tree gets the four-wave kernel; this one is known to be a good tree (see the tuning key)
-            args.tuning = (args.tuning + "," if args.tuning else "") + "waves_per_simd=3"
         if args.tuning:  # before the scene goes in: some settings steer the device BVH builder
             g.set_tuning(**{k: int(v) for k, v in (item.split("=") for item in args.tuning.split(","))})
         install_scene(g, work)

@@ -65,16 +65,21 @@ constexpr unsigned kMegaTile = kMegaThreads == 64 ? 8u : 16u;  // tile edge in p
 // distance ties or narrowly beats the current best from being culled with its box.
 constexpr float kPruneMargin = 1.0009765625f;  // 1 + 2^-10
 
-// Slab test with the shader's return convention (intersection.glsl:63-77): entry distance, or
-// exit distance when the origin is inside, or -1 on a miss.  t0 is also returned for pruning.
-PT_DEV float hitAabb(v3 o, v3 inv, float minx, float miny, float minz, float maxx, float maxy, float maxz, float& t0out)
+// Slab test of intersection.glsl:63-77.  The shader returns the entry distance, or the exit distance
+// when the origin is inside, or -1 on a miss, and its callers test that value for `> 0`; with t1 >= t0
+// (no miss) that value is positive exactly when t1 is, so the hit decision is taken from t0 and t1
+// directly.  `dist` is the shader's return value of a hit (the children are ordered by it), `t0out` the
+// entry distance (for pruning).
+PT_DEV bool hitAabb(v3 o, v3 inv, float minx, float miny, float minz, float maxx, float maxy, float maxz, float& dist,
+                    float& t0out)
 {
     float fx = (maxx - o.x) * inv.x, fy = (maxy - o.y) * inv.y, fz = (maxz - o.z) * inv.z;
     float nx = (minx - o.x) * inv.x, ny = (miny - o.y) * inv.y, nz = (minz - o.z) * inv.z;
     float t1 = fmin_(fmax_(fx, nx), fmin_(fmax_(fy, ny), fmax_(fz, nz)));
     float t0 = fmax_(fmin_(fx, nx), fmax_(fmin_(fy, ny), fmin_(fz, nz)));
     t0out = t0;
-    return (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
+    dist = (t0 > 0.0f) ? t0 : t1;
+    return (t1 >= t0) & (t1 > 0.0f);
 }
 
 // ------------------------------------------------------------------------------ BVH query
@@ -138,6 +143,18 @@ PT_DEV int stackGet(const int* stack, const int* deep, int i)
     return v;
 }
 
+// The stack: `top` is the newest entry (0 when there is none), row k of the column holds what was
+// `top` when the k-th entry was pushed, so row 0 always holds 0 and a pop needs no test for an empty
+// stack: it takes `top`, steps `sp` down (not below 0) and reloads `top` from row `sp`.  Row 0 is
+// zeroed once by the kernel; the first push of every query rewrites it with the same 0.
+template <int STRIDE, int LDS_DEPTH>
+PT_DEV void stackPop(Query& q, const int* stack, const int* deep)
+{
+    q.cur = q.top;
+    q.sp = q.sp > 0 ? q.sp - 1 : 0;
+    q.top = stackGet<STRIDE, LDS_DEPTH>(stack, deep, q.sp);
+}
+
 template <bool COUNT, int STRIDE = kBlockThreads, int LDS_DEPTH = 0>
 PT_DEV bool queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc, int* deep = nullptr)
 {
@@ -154,23 +171,23 @@ PT_DEV bool queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc,
     bool pop = false;
     if (hasNode) {
         if (COUNT) sc.nodeVisits++;
-        float t0l, t0r;
-        const float dl = hitAabb(q.ro, q.inv, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, t0l);
-        const float dr = hitAabb(q.ro, q.inv, n2.x, n2.y, n2.z, n3.x, n3.y, n3.z, t0r);
+        float dl, dr, t0l, t0r;
+        const bool inl = hitAabb(q.ro, q.inv, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, dl, t0l);
+        const bool inr = hitAabb(q.ro, q.inv, n2.x, n2.y, n2.z, n3.x, n3.y, n3.z, dr, t0r);
         const float limit = q.bestT * kPruneMargin;  // bestT stays FLT_MAX for shadow rays
-        const bool hl = dl > 0.0f && !(t0l > limit);
-        const bool hr = dr > 0.0f && !(t0r > limit);
+        const bool hl = inl & !(t0l > limit);
+        const bool hr = inr & !(t0r > limit);
         const int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
-        const bool both = hl && hr;
-        const bool leftFirst = dl < dr;  // intersection.glsl:169-180
+        const bool both = hl & hr;
+        const bool leftFirst = dl < dr;  // intersection.glsl:169-180 (both children hit: the shader's values)
         if (both) {  // postpone the far child
-            if (q.sp > 0) stackPut<STRIDE, LDS_DEPTH>(stack, deep, q.sp - 1, q.top);
+            stackPut<STRIDE, LDS_DEPTH>(stack, deep, q.sp, q.top);
             q.top = leftFirst ? right : left;
             q.sp++;
             if (COUNT) sc.maxStack = (unsigned)q.sp > sc.maxStack ? (unsigned)q.sp : sc.maxStack;
         }
         q.cur = both ? (leftFirst ? left : right) : (hl ? left : right);
-        pop = !(hl || hr);
+        pop = !(hl | hr);
     }
     if (doTri) {
         // Moller-Trumbore with the shader's expressions (intersection.glsl:26-40); the edges and
@@ -186,8 +203,8 @@ PT_DEV bool queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc,
         const float u = dot(ac, dao) * invDet;
         const float v = -dot(ab, dao) * invDet;
         const float w = 1.0f - u - v;
-        const bool ok = det >= 1e-10f && dst >= 0.0f && u >= 0.0f && v >= 0.0f && w >= 0.0f;
-        const bool better = ok && (q.isShadow || dst < q.bestT);
+        const bool ok = (det >= 1e-10f) & (dst >= 0.0f) & (u >= 0.0f) & (v >= 0.0f) & (w >= 0.0f);
+        const bool better = ok & (q.isShadow | (dst < q.bestT));
         q.bestT = better ? dst : q.bestT;
         q.bestU = better ? u : q.bestU;
         q.bestV = better ? v : q.bestV;
@@ -195,18 +212,12 @@ PT_DEV bool queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc,
         q.leafPos++;
         finished = q.isShadow && ok;  // occluded
     }
-    if (pop) {  // both children missed: next sub-tree off the stack
-        q.cur = q.sp > 0 ? q.top : 0;
-        q.sp = q.sp > 0 ? q.sp - 1 : 0;
-        if (q.sp > 0) q.top = stackGet<STRIDE, LDS_DEPTH>(stack, deep, q.sp - 1);
-    }
+    if (pop) stackPop<STRIDE, LDS_DEPTH>(q, stack, deep);  // both children missed: next sub-tree off the stack
     if (q.cur < 0 && q.leafPos == q.leafEnd) {  // park the leaf `cur` refers to, walk on
         const unsigned bits = ~(unsigned)q.cur;
         q.leafPos = bits >> 3;
         q.leafEnd = q.leafPos + (bits & 7u) + 1u;
-        q.cur = q.sp > 0 ? q.top : 0;
-        q.sp = q.sp > 0 ? q.sp - 1 : 0;
-        if (q.sp > 0) q.top = stackGet<STRIDE, LDS_DEPTH>(stack, deep, q.sp - 1);
+        stackPop<STRIDE, LDS_DEPTH>(q, stack, deep);
     }
     return finished || (q.cur == 0 && q.leafPos == q.leafEnd);
 }
@@ -499,6 +510,7 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
     __shared__ unsigned s_pixel[64];  // the tile's pixels that lie inside the image, compacted
     const unsigned lane = threadIdx.x;
     int* stack = s_stack + lane;
+    stack[0] = 0;  // row 0 of the stack column: "no entry"
 
     // Consecutive blocks go to different XCDs, so any block -> tile map that does not cluster
     // expensive tiles on one XCD keeps the eight of them equally loaded: row-major order without
@@ -846,6 +858,7 @@ __global__ __launch_bounds__(kBlockThreads) void traverseKernel(DevParams P, Dev
     __shared__ unsigned s_done[kBlockThreads / 64][128];
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     int* stack = s_stack + tid;
+    stack[0] = 0;  // row 0 of the stack column: "no entry"
     volatile unsigned* done = s_done[wave];
     const unsigned total = *Q.rayInCount;
     // Queue entries are reserved a chunk at a time per wave and handed to idle lanes from the

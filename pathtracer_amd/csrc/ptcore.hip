@@ -127,8 +127,7 @@ struct pt_ctx {
     // finished samples of one launch, 48 B per (sample, pixel); resolved into the images after the launch
     DeviceBuffer dSamples;
     uint64_t sampleBudgetBytes = 8ull << 30;
-    bool qualityTree = false;  // the tree in use was built by this library's own builders (uncapped sweep, device)
-    int wavesPerSimd = 0;      // megakernel variant: 3 or 4 waves per SIMD, 0 = by qualityTree
+    int wavesPerSimd = 0;      // megakernel variant: 3 or 4 waves per SIMD (0: the default, 3)
     bool rebuildOnUpload = false;  // pt_upload_nodes' tree is replaced by the device builder's over the same primitives
     int plocRadius = 32;  // device BVH builder: neighbours searched on either side per clustering round (0: Morton radix tree)
     bool deepStackInLds = false;  // trees deeper than 32 levels: whole stack in LDS (12/16 KB per wave)
@@ -439,11 +438,10 @@ void launchTrace(const pt_ctx* c, const DevParams& P, const DevScene& S, const I
     // on a 5 M-triangle scene whose tree is 34 deep; a 40-entry LDS stack, 15 waves per CU, costs
     // 6 %, a 48-entry one 13 %), or (deepStackInLds, for A/B) get a 12 or 16 KB LDS stack.
     const int stackClass = c->maxDepth <= 32 ? 0 : (!c->deepStackInLds ? 3 : (c->maxDepth <= 48 ? 1 : 2));
-    // Three waves per SIMD (more registers, a quarter of the spills) for trees built by this library's
-    // own builders, four for uploaded ones: with few node visits per ray the shading blocks, where the
-    // spills are, weigh more (8.7 % faster at three on the benchmark scene's device-built tree, 0.8 %
-    // slower on the reference's tree of the same scene).
-    const bool three = c->wavesPerSimd == 3 || (c->wavesPerSimd == 0 && c->qualityTree);
+    // Three waves per SIMD (168 VGPRs, nothing spilled) unless four are asked for (128 VGPRs, 66 values
+    // spilled in the shading blocks): three are 2 % faster on the reference's tree of the benchmark scene
+    // and 10 % faster on the trees of this library's own builders, where shading weighs more.
+    const bool three = c->wavesPerSimd != 4;
 #define PT_LAUNCH_TRACE(COUNTED)                                                                                                 \
     do {                                                                                                                         \
         if (stackClass == 3 && three) hipLaunchKernelGGL((renderKernel<32, 32, COUNTED, 3>), grid, block, 0, c->stream, P, S, img, ctr); \
@@ -707,7 +705,6 @@ int pt_upload_nodes(pt_ctx* c, const void* nodes48, size_t count)
     c->nodes.assign(p, p + count);
     c->geometryDirty = true;
     c->deviceGeometry = false;
-    c->qualityTree = false;
     c->tileCostValid = false;
     return PT_OK;
 }
@@ -720,7 +717,6 @@ int pt_upload_primitives(pt_ctx* c, const void* prims112, size_t count)
     c->prims.assign(p, p + count);
     c->geometryDirty = true;
     c->deviceGeometry = false;
-    c->qualityTree = false;
     c->tileCostValid = false;
     return PT_OK;
 }
@@ -857,7 +853,6 @@ int processBuffers(pt_ctx* c, bool uncapped)
     rc = pt_upload_nodes(c, nodesAligned.data(), nodesAligned.size());
     if (rc != PT_OK) return rc;
     rc = pt_upload_primitives(c, primsAligned.data(), primsAligned.size());
-    c->qualityTree = rc == PT_OK && uncapped;
     return rc;
 }
 
@@ -1268,7 +1263,7 @@ int pt_scene_bytes(pt_ctx* c, uint64_t* nodeBytes, uint64_t* triangleBytes, uint
 // cut into launches whose sample records fit); 9: trees deeper than 32 levels keep their whole traversal
 // stack in LDS (1) instead of 32 entries there and the rest in private memory (0, the default); 10: device BVH
 // builder: clustering search radius (0 = Morton radix tree); 11: megakernel compiled for 3 or 4 waves per SIMD
-// (0 = 3 for trees of this library's own builders, 4 for uploaded ones).
+// (0 = the default, 3).
 int pt_debug_set_tuning(pt_ctx* c, int key, int value)
 {
     if (!c) return fail(PT_ERR_INVALID, "null context");
@@ -1611,7 +1606,6 @@ int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count)
     c->maxDepth = height;
     c->tileCostValid = false;
     c->deviceGeometry = true;
-    c->qualityTree = c->plocRadius > 0;
     c->geometryDirty = false;
     c->nodes.clear();
     c->prims.clear();
