@@ -141,9 +141,9 @@ struct pt_ctx {
     float4* bound[3] = {nullptr, nullptr, nullptr};
     int32_t rootRef = 0;
     int maxDepth = 0;
-    uint32_t travExitNum = 28;  // of 64
+    uint32_t travExitNum = 32;  // of 64
     uint32_t refillMin = 16;
-    uint32_t hitMinNum = 20;
+    uint32_t hitMinNum = 16;
     int pipeline = 0;    // 0 = megakernel, 1 = wavefront
     int checkEvery = 2;  // wavefront: read the live-ray count back every this many iterations
     int traverseBlocks = 0;

@@ -46,10 +46,17 @@ PT_DEV unsigned nextRandom(unsigned& state)
 PT_DEV float randomValue(unsigned& state) { return (float)nextRandom(state) / 4294967295.0f; }
 
 // ---- texture(): bilinear, REPEAT, base level, float weights
+// i mod n (REPEAT addressing).  Nearly every index lies within one period of [0, n): one add or
+// subtract settles those, and the integer division (some 35 instructions) is left to the lanes that
+// really are further out.
 PT_DEV int wrapIndex(int i, int n)
 {
-    int m = i % n;
-    return m < 0 ? m + n : m;
+    int m = i < 0 ? i + n : (i >= n ? i - n : i);
+    if (__builtin_expect((unsigned)m >= (unsigned)n, 0)) {
+        m = i % n;
+        m = m < 0 ? m + n : m;
+    }
+    return m;
 }
 struct Bilerp {
     int x0, x1, y0, y1;
