@@ -328,7 +328,10 @@ def main():
         # them synchronises this rank's stream (part of the measured time, as a real caller would)
         s = g.stats()
         rays += s.rays_closest + s.rays_any
-        kernel_ms.append(g.last_kernel_ms())
+        try:
+            kernel_ms.append(g.last_kernel_ms())
+        except Exception:  # the wavefront pipeline (--tuning pipeline=1) has no single trace kernel: whole dispatch
+            kernel_ms.append((g.last_dispatch_ms(), 0.0))
     if not args.reduce_every_step:
         sr.reduce()  # one collective per render (the K steps)
     sync()
@@ -413,7 +416,7 @@ def main():
                 "waves_per_simd": pmc.get("waves_per_simd") if pmc else None,
                 "l2_hit": pmc.get("l2_hit") if pmc else None,
                 "pmc_source": pmc.get("source") if pmc else None,
-                "kernel": "renderKernel",
+                "kernel": "renderKernel" if avg_resolve_s > 0 else "traverseKernel + shadeKernel (whole dispatch)",
                 "kernel_ms_avg": avg_kernel_s * 1e3,
                 "algorithmic_bytes_per_ray": bytes_per_ray,
                 "rays_per_launch": rays_step,
@@ -421,9 +424,9 @@ def main():
                 "triangle_tests_per_ray": st.triangle_tests / rays_step,
                 "max_stack_depth": st.max_stack_depth,
                 "scene_bytes": scene_bytes,
-                "resolve_kernel": {"kernel_ms_avg": avg_resolve_s * 1e3, "algorithmic_bytes": resolve_bytes,
-                                   "achieved": resolve_bytes / avg_resolve_s / 1e9, "unit": "GB/s", "bound": "hbm",
-                                   "frac": resolve_bytes / avg_resolve_s / 1e9 / HBM_PEAK_GBS},
+                "resolve_kernel": ({"kernel_ms_avg": avg_resolve_s * 1e3, "algorithmic_bytes": resolve_bytes,
+                                    "achieved": resolve_bytes / avg_resolve_s / 1e9, "unit": "GB/s", "bound": "hbm",
+                                    "frac": resolve_bytes / avg_resolve_s / 1e9 / HBM_PEAK_GBS} if avg_resolve_s > 0 else None),
             },
         }
         if world == 1 and args.bvh == "host" and args.copies == 1 and not args.no_device_tree and not args.stub:

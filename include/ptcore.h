@@ -347,6 +347,10 @@ int pt_debug_set_tuning(pt_ctx* ctx, int key, int value);
  * [10] lanes finishing a sample, [11] lanes starting a sample, [12] shader clock ticks waves spent in
  * shading phases, [13] in traversal phases, [14] of [12] in the hit block, [15] of [12] in the miss block. */
 int pt_debug_get_profile(pt_ctx* ctx, uint64_t out16[16]);
+/* Profiling hook (no counterpart in the reference): closest-hit queries of the most recent
+ * pt_dispatch_counted() under the megakernel scheduler by path depth: [0] primary rays, [1] the rays
+ * after the first bounce, ...; depths past 31 are counted in [31]. */
+int pt_debug_get_depth_histogram(pt_ctx* ctx, uint64_t out32[32]);
 /* Profiling hook (no counterpart in the reference): device wall-clock ticks at the start and end of every
  * wave of the most recent pt_dispatch_counted() under the megakernel scheduler, as (start, end) pairs
  * per block of the grid (start = 0: the block found no work); *clock_khz_out = tick rate.  NULL pairs_out

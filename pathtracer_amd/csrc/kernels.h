@@ -163,8 +163,15 @@ PT_DEV bool queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc,
     // Both records are requested up front by every calling lane -- record 0 of either array (always
     // allocated) stands in when the lane has no node or no leaf -- so the loads sit in straight-line
     // code and are all in flight before the first use.
-    const float4* nrec = reinterpret_cast<const float4*>(S.nodes + (hasNode ? q.cur : 0));
-    const float4* trec = reinterpret_cast<const float4*>(S.triangles + (doTri ? q.leafPos : 0u));
+    // (32-bit byte offsets from the array bases: the loads then take a scalar base and a 32-bit lane
+    // offset, with no 64-bit address arithmetic in the loop; the host refuses arrays beyond 4 GB)
+    const unsigned nodeOff = (hasNode ? (unsigned)q.cur : 0u) << 6;
+    const unsigned triIdx16 = (doTri ? q.leafPos : 0u) << 4;
+    unsigned triOff;  // x 48 as one full-rate shift-add (the compiler would fold it into a quarter-rate 32-bit multiply)
+    asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(triOff) : "v"(triIdx16));
+    static_assert(sizeof(DevNode) == 64 && sizeof(DevTriangle) == 48, "record sizes are wired into the offsets above");
+    const float4* nrec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + nodeOff);
+    const float4* trec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.triangles) + triOff);
     const float4 n0 = nrec[0], n1 = nrec[1], n2 = nrec[2], n3 = nrec[3];
     const float4 t0 = trec[0], t1 = trec[1], t2 = trec[2];
     bool finished = false;  // query complete
@@ -508,7 +515,9 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
     __shared__ int s_stack[STACK * kMegaThreads];
     int deepStack[DEEP > 0 ? DEEP : 1];
     __shared__ unsigned s_pixel[64];  // the tile's pixels that lie inside the image, compacted
+    __shared__ unsigned s_depth[COUNT ? 32 : 1];  // counting build: closest-hit queries by path depth
     const unsigned lane = threadIdx.x;
+    if (COUNT && lane < 32u) s_depth[lane] = 0u;
     int* stack = s_stack + lane;
     stack[0] = 0;  // row 0 of the stack column: "no entry"
 
@@ -599,6 +608,7 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
                 mode = kModeTrav;
             } else if (br.hasExt) {
                 nRays++;
+                if (COUNT) atomicAdd(&s_depth[ps.bounce < 31u ? ps.bounce : 31u], 1u);
                 beginQuery(q, P.rootRef, br.origin, br.extDir, false);
                 mode = kModeTrav;
             }
@@ -633,6 +643,7 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
                     hasExt = false;
                     nSamples++;
                     nRays++;
+                    if (COUNT) atomicAdd(&s_depth[0], 1u);
                     beginQuery(q, P.rootRef, ro, rd, false);
                     mode = kModeTrav;
                 } else {
@@ -674,6 +685,7 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
                         if (q.bestPrim < 0) ps.radiance = ps.radiance + pending;  // unoccluded
                         if (hasExt) {
                             nRays++;
+                            if (COUNT) atomicAdd(&s_depth[ps.bounce < 31u ? ps.bounce : 31u], 1u);
                             hasExt = false;
                             beginQuery(q, P.rootRef, q.ro, extDir, false);
                         } else {
@@ -711,6 +723,8 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
             atomicAdd(&counters->triangleTests, (unsigned long long)sTris);
             atomicMax(&counters->maxStack, m);
             for (int i = 0; i < 16; i++) atomicAdd(&counters->profile[i], prof[i]);
+            for (int i = 0; i < 32; i++)
+                if (s_depth[i]) atomicAdd(&counters->depthRays[i], (unsigned long long)s_depth[i]);
             if (P.waveTimes && kCount) {
                 P.waveTimes[2 * (size_t)blockIdx.x] = waveStart;
                 P.waveTimes[2 * (size_t)blockIdx.x + 1] = wall_clock64();

@@ -178,6 +178,9 @@ struct DevCounters {
     // shading a hit, [8] lanes shading a miss, [9] shading phases, [10] lanes finishing a sample,
     // [11] lanes starting a sample
     unsigned long long profile[16];
+    // counting build of the megakernel: closest-hit queries by path depth (primary rays in [0], the ray
+    // after the first bounce in [1], ...; depths past 31 in [31])
+    unsigned long long depthRays[32];
 };
 
 }  // namespace ptcore

@@ -208,6 +208,8 @@ int syncScene(pt_ctx* c)
             return fail(PT_ERR_SCENE, "BVH is " + std::to_string(packed.maxDepth) + " interior levels deep; the traversal stack holds 64");
         const size_t nb = packed.nodes.size() * sizeof(DevNode), tb = packed.triangles.size() * sizeof(DevTriangle),
                      sb = packed.shading.size() * sizeof(DevShading);
+        if (nb >= (1ull << 32) || tb >= (1ull << 32))
+            return fail(PT_ERR_SCENE, "node or triangle array of 4 GB or more (the kernels address records by 32-bit byte offsets)");
         HIP_TRY(c->dNodes.ensure(nb));
         HIP_TRY(c->dTriangles.ensure(tb));
         HIP_TRY(c->dShading.ensure(sb));
@@ -1350,6 +1352,19 @@ int pt_debug_get_profile(pt_ctx* c, uint64_t out16[16])
     return PT_OK;
 }
 
+// Profiling hook: closest-hit queries by path depth of the most recent pt_dispatch_counted() with the
+// megakernel scheduler (primary rays in [0]; depths past 31 in [31]).
+int pt_debug_get_depth_histogram(pt_ctx* c, uint64_t out32[32])
+{
+    if (!c || !out32) return fail(PT_ERR_INVALID, "null argument");
+    DeviceGuard guard(c->device);
+    DevCounters h{};
+    HIP_TRY(hipMemcpyAsync(&h, c->dCounters.ptr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 32; i++) out32[i] = h.depthRays[i];
+    return PT_OK;
+}
+
 // Test hook (not part of the drop-in surface): evaluates one float32 building block of the
 // kernels element-wise on the device.  fn: 0 sin, 1 cos, 2 asin, 3 atan2(a,b), 4 pow(a,b),
 // 5 min, 6 max, 7 a/b, 8 sqrt, 9 1/sqrt.
@@ -1483,7 +1498,8 @@ int buildPlocTopology(pt_ctx* c, LbvhScratch& w, const RefPrimitiveAlign* dIn, i
 int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count)
 {
     if (count == 0) return fail(PT_ERR_INVALID, "no primitives");
-    if (count >= (1u << 27)) return fail(PT_ERR_INVALID, "too many primitives (limit 2^27)");
+    // (the kernels address node and triangle records by 32-bit byte offsets: both arrays stay below 4 GB)
+    if (count >= (1u << 26)) return fail(PT_ERR_INVALID, "too many primitives (limit 2^26)");
     DeviceGuard guard(c->device);
     // The build writes into the live geometry buffers and can still fail after that: from here until it
     // succeeds the context has no geometry (a dispatch returns PT_ERR_STATE, never an old tree over new

@@ -133,6 +133,7 @@ SYMBOLS = {
                                       ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "pt_debug_set_tuning": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "pt_debug_get_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]),
+    "pt_debug_get_depth_histogram": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]),
     "pt_debug_get_wave_times": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t,
                                                ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]),
     "pt_debug_eval_math": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,

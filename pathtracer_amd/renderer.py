@@ -146,6 +146,12 @@ class Renderer:
         check(self._lib.pt_debug_get_profile(self._h, out))
         return list(out)
 
+    def depth_histogram(self):
+        """Closest-hit queries by path depth of the last counted megakernel dispatch (primary rays first)."""
+        out = (ctypes.c_uint64 * 32)()
+        check(self._lib.pt_debug_get_depth_histogram(self._h, out))
+        return list(out)
+
     def wave_times(self):
         """-> ((n, 2) uint64 start/end ticks per block of the grid (start 0: the block found no work), tick rate
         in kHz) of the last counted dispatch."""

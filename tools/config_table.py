@@ -20,6 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--spp", type=int, default=64)
 ap.add_argument("--bvh", choices=["host", "full-sweep", "device"], default="host",
                 help="host: the reference's builder; full-sweep: the same without its cost cap; device: GPU linear BVH")
+ap.add_argument("--depths", action="store_true", help="also print the share of paths alive at each depth (counting build)")
 ap.add_argument("--tuning", default="", help="scheduler settings: key=value,key=value (Renderer.set_tuning)")
 args = ap.parse_args()
 
@@ -63,10 +64,14 @@ def run(name, width, height, bounces, meshes, mats, textures=(), eye=None, look_
     g.dispatch(1, args.spp, 1, counted=True)
     g.synchronize()
     st, pr = g.stats(), g.profile()
+    depth = g.depth_histogram()
     print(f"{name:34s} {tris:8d} triangles {width}x{height} {bounces:2d} bounces {args.spp} spp: {t:8.2f} ms  "
           f"{rays / t / 1e3:8.1f} Mrays/s  {args.spp / t * 1e3:8.1f} spp/s  {rays / (width * height * args.spp):.2f} rays/sample  "
           f"{st.node_visits / rays:5.1f} visits + {st.triangle_tests / rays:4.1f} tests per ray  "
           f"lanes per traversal iteration {pr[1] / max(pr[0], 1):4.1f}, per hit block {pr[7] / max(pr[6], 1):4.1f}")
+    if args.depths:  # share of the samples whose path is still alive at each depth (closest-hit queries per sample)
+        alive = [d / max(depth[0], 1) for d in depth[:bounces + 1]]
+        print(" " * 34 + " paths alive by depth: " + " ".join(f"{a:.3f}" for a in alive if a > 0))
 
 
 m, a = scenes.flatten(scenes.recipe("BunnyClearcoat"))
@@ -76,6 +81,8 @@ m, a = scenes.flatten(scenes.recipe("DragonGlass"))
 v, i = scenes.subdivide(*m[0], 1)
 run("DragonGlass stand-in, 3 bounces", 1920, 1080, 3, [(v, i), m[1]], a)
 run("DragonGlass stand-in, 8 bounces", 1920, 1080, 8, [(v, i), m[1]], a)
+# the same scene from close by: the glass mesh fills most of the frame (the reference camera sees mostly floor and sky)
+run("DragonGlass stand-in, close-up", 1920, 1080, 8, [(v, i), m[1]], a, eye=(-0.15, 0.8, 0.85), look_at=(-0.15, 0.8, 0.0))
 m, a, tex, _ = recipes.load_scene("Mill")
 run("Mill (3 textures)", 1920, 1080, 8, m, a, tex, eye=(14.0, 9.0, 16.0), look_at=(0.0, 5.0, 0.0))
 m, a, tex, _ = recipes.load_scene("AreaLight")
