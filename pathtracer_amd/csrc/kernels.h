@@ -96,11 +96,14 @@ struct StepCounters {
     unsigned nodeVisits, triangleTests, maxStack;
 };
 
-PT_DEV void beginQuery(Query& q, int rootRef, v3 ro, v3 rd, bool isShadow)
+PT_DEV v3 reciprocal3(v3 d) { return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
+
+// `inv` = reciprocal3(rd), for callers that have it at hand.
+PT_DEV void beginQuery(Query& q, int rootRef, v3 ro, v3 rd, v3 inv, bool isShadow)
 {
     q.ro = ro;
     q.rd = rd;
-    q.inv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    q.inv = inv;
     q.bestT = kFltMax;
     q.bestU = 0.0f;
     q.bestV = 0.0f;
@@ -111,6 +114,7 @@ PT_DEV void beginQuery(Query& q, int rootRef, v3 ro, v3 rd, bool isShadow)
     q.leafPos = q.leafEnd = 0;
     q.isShadow = isShadow;
 }
+PT_DEV void beginQuery(Query& q, int rootRef, v3 ro, v3 rd, bool isShadow) { beginQuery(q, rootRef, ro, rd, reciprocal3(rd), isShadow); }
 
 // Advances the query by one iteration and returns true when the query is complete.  A lane can
 // hold an interior node to visit (`cur` > 0) and, next to it, a leaf whose triangles are still
@@ -559,7 +563,8 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
     unsigned pixel = 0;  // which pixel of the tile (0..63, row-major) the lane's current sample belongs to
     int mode = kModeNew;
     Query q{};
-    v3 extDir = splat(0.0f);   // direction of the extension ray waiting behind a shadow ray
+    v3 extDir = splat(0.0f);   // direction of the extension ray waiting behind a shadow ray ...
+    v3 extInv = splat(0.0f);   // ... and its reciprocal: the divisions are done in the hit block, not at the restart inside the traversal loop
     v3 pending = splat(0.0f);  // NEE contribution, added if the shadow ray is unoccluded
     bool hasExt = false;
 
@@ -604,6 +609,7 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
                 pending = br.pending;
                 hasExt = br.hasExt;
                 extDir = br.extDir;
+                extInv = reciprocal3(br.extDir);
                 beginQuery(q, P.rootRef, br.origin, br.shadowDir, true);
                 mode = kModeTrav;
             } else if (br.hasExt) {
@@ -687,7 +693,7 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
                             nRays++;
                             if (COUNT) atomicAdd(&s_depth[ps.bounce < 31u ? ps.bounce : 31u], 1u);
                             hasExt = false;
-                            beginQuery(q, P.rootRef, q.ro, extDir, false);
+                            beginQuery(q, P.rootRef, q.ro, extDir, extInv, false);
                         } else {
                             mode = kModeFinish;
                         }
