@@ -18,7 +18,7 @@
 extern "C" void ref_calculate_hdri_cache(const float* hdri_rgb, int width, int height, float* cache_out)
 {
     std::vector<float> textureData(hdri_rgb, hdri_rgb + (size_t)width * height * 3);
-#include "_ref/hdri_cache_803_901.inc"
+#include "hdri_cache_803_901.inc"
     std::memcpy(cache_out, cache, sizeof(float) * (size_t)width * height * 3);
     delete[] cache;
 }
