@@ -204,7 +204,10 @@ int pt_process_buffers_full_sweep(pt_ctx* ctx);
  * far below the reference's capped one), images differ from the reference's only where distances
  * tie exactly.  prims112: `count` unsorted BvhPrimitiveAlign records (host memory); the call uploads
  * them, builds and installs the geometry in place of pt_upload_nodes + pt_upload_primitives.
- * PT_ERR_SCENE if the tree comes out deeper than the traversal stack (64 levels). */
+ * PT_ERR_SCENE if the tree comes out deeper than the traversal stack (64 levels); PT_ERR_INVALID for
+ * 2^26 primitives or more (the kernels address node and triangle records by 32-bit byte offsets, so
+ * either array stays below 4 GB; an uploaded tree of that size is refused with PT_ERR_SCENE at the
+ * first dispatch). */
 int pt_build_bvh_device(pt_ctx* ctx, const void* prims112, size_t count);
 /* pt_process_buffers with the GPU builder in place of BuildBvhWithSah. */
 int pt_process_buffers_device(pt_ctx* ctx);
@@ -335,8 +338,7 @@ int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, 
  * into launches that fit; default 8192); 9: trees deeper than 32 levels keep their whole traversal stack
  * in LDS (1) instead of 32 entries there and the rest in lane-private memory (0, the default); 10: device
  * BVH builder: clusters searched on either side per round (default 32; 0 = Morton radix tree instead);
- * 11: megakernel variant compiled for 3 or 4 resident waves per SIMD (default 0: 3 for trees made by
- * pt_process_buffers_full_sweep / pt_build_bvh_device, 4 for uploaded trees). */
+ * 11: megakernel variant compiled for 3 or 4 resident waves per SIMD (default 0: 3). */
 int pt_debug_set_tuning(pt_ctx* ctx, int key, int value);
 
 /* Profiling hook, not part of the drop-in surface (no counterpart in the reference): wave-level

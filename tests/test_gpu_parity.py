@@ -123,6 +123,10 @@ def test_small_scene_all_lobes_bit_exact(pipeline):
     # shadow queries whose contribution is exactly zero are not issued
     assert 0 < st.rays_any <= cpu[4].rays_any
     assert st.node_visits <= cpu[4].pair_tests and st.triangle_tests <= cpu[4].triangle_tests
+    if pipeline == 0:  # the megakernel's counting build also sorts the closest-hit queries by path depth
+        depth = g.depth_histogram()
+        assert sum(depth) == st.rays_closest and depth[0] == st.samples
+        assert all(a >= b for a, b in zip(depth, depth[1:])) and sum(depth[p.max_bounces:]) == 0
     assert np.isfinite(gpu[0]).all() and gpu[0][..., :3].mean() > 0.01
 
 
