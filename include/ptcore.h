@@ -326,10 +326,10 @@ int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, 
 
 /* Tuning hook, not part of the drop-in surface (no counterpart in the reference).  key 0: scheduler
  * (0 = single-launch megakernel, the default; 1 = wavefront pipeline); 1: megakernel traversal-phase
- * exit threshold in 64ths of the live lanes (default 28); 2: wavefront refill threshold in idle
+ * exit threshold in 64ths of the lanes that entered the phase (default 32); 2: wavefront refill threshold in idle
  * lanes (default 16); 3: wavefront iterations between read-backs of the live-ray count (default 2);
  * 4: traverse grid size in blocks (0 = sized from the occupancy query); 5: megakernel hit-shading
- * threshold in 64ths of the live lanes (default 20): hits wait until that share of the wave holds one;
+ * threshold in 64ths of the live lanes (default 16): hits wait until that share of the wave holds one;
  * 6: costliest-block-first launch order from the previous launch's per-tile cost (default 1); 7: tile
  * split: a tile whose cost exceeds 1/value of the launch's lower bound (total cost / resident waves) has
  * its samples spread over several blocks; 0 = one block per tile; -1 (default) = 2 for images with no
