@@ -25,7 +25,10 @@
 
 namespace ptcore {
 
-constexpr int kLbvhLeafMax = 4;  // BVH::BuildBvhWithSah is called with leaf size 4 (PathTracingRenderer.cpp:583)
+#ifndef PT_LBVH_LEAF_MAX
+#define PT_LBVH_LEAF_MAX 4
+#endif
+constexpr int kLbvhLeafMax = PT_LBVH_LEAF_MAX;  // BVH::BuildBvhWithSah is called with leaf size 4 (PathTracingRenderer.cpp:583)
 
 struct LbvhBounds {
     unsigned int lo[3], hi[3];  // order-preserving encodings of floats

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times alternative builds of libptcore.so on the benchmark workload, one subprocess per build
-(a process can only load one copy of the library).  python tools/ab_libs.py lib1.so lib2.so ..."""
+(a process can only load one copy of the library).  python tools/ab_libs.py [--bvh device] lib1.so lib2.so ..."""
 import os
 import subprocess
 import sys
@@ -14,10 +14,12 @@ from pathtracer_amd import lib as L
 L.LIB_PATH = sys.argv[1]
 import bench
 from pathtracer_amd import renderer as R
-class A: subdivide = bench.DEFAULT_SUBDIVIDE
+class A: subdivide = bench.DEFAULT_SUBDIVIDE; bvh = os.environ.get("PT_AB_BVH", "host")
 work = bench.build_workload(A)
 g = R.Renderer(1920, 1080)
-g.upload_nodes(work["nodes"]); g.upload_primitives(work["prims"]); g.upload_materials(work["mats"]); g.upload_environment(work["hdri"], work["cache"])
+if work["nodes"] is None: g.build_bvh_device(work["prims"])
+else: g.upload_nodes(work["nodes"]); g.upload_primitives(work["prims"])
+g.upload_materials(work["mats"]); g.upload_environment(work["hdri"], work["cache"])
 p = R.default_params(1920, 1080); p.max_bounces = 8; g.set_params(p)
 g.dispatch(1, 2, 1); g.synchronize()
 ms = []
@@ -26,5 +28,9 @@ for r in range(4):
 st = g.stats(); rays = st.rays_closest + st.rays_any
 print("%%-50s median %%8.3f ms  min %%8.3f  -> %%8.1f Mrays/s" %% (os.path.basename(sys.argv[1]), np.median(ms), min(ms), rays / np.median(ms) / 1e3))
 ''' % ROOT
-for lib in sys.argv[1:]:
+libs = sys.argv[1:]
+if libs[:1] == ["--bvh"]:
+    os.environ["PT_AB_BVH"] = libs[1]
+    libs = libs[2:]
+for lib in libs:
     subprocess.run([sys.executable, "-c", CODE, os.path.abspath(lib)], check=True)
