@@ -116,7 +116,11 @@ PT_DEV void beginQuery(Query& q, int rootRef, v3 ro, v3 rd, v3 inv, bool isShado
 }
 PT_DEV void beginQuery(Query& q, int rootRef, v3 ro, v3 rd, bool isShadow) { beginQuery(q, rootRef, ro, rd, reciprocal3(rd), isShadow); }
 
-// Advances the query by one iteration and returns true when the query is complete.  A lane can
+// What queryStep reports: the query goes on, it is complete (a closest-hit query's result is in best*,
+// a shadow query found no occluder), or a shadow query met an occluder (and is complete).
+enum QueryState : int { kQueryGoesOn = 0, kQueryDone = 1, kQueryOccluded = 2 };
+
+// Advances the query by one iteration and reports its state.  A lane can
 // hold an interior node to visit (`cur` > 0) and, next to it, a leaf whose triangles are still
 // being scanned (`leafPos` < `leafEnd`): reaching a leaf does not interrupt the walk, the leaf is
 // parked and its triangles are tested one per iteration while the lane goes on visiting nodes.  A
@@ -160,7 +164,7 @@ PT_DEV void stackPop(Query& q, const int* stack, const int* deep)
 }
 
 template <bool COUNT, int STRIDE = kBlockThreads, int LDS_DEPTH = 0>
-PT_DEV bool queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc, int* deep = nullptr)
+PT_DEV int queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc, int* deep = nullptr)
 {
     const bool hasNode = q.cur > 0;
     const bool doTri = q.leafPos < q.leafEnd;
@@ -215,13 +219,14 @@ PT_DEV bool queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc,
         const float v = -dot(ab, dao) * invDet;
         const float w = 1.0f - u - v;
         const bool ok = (det >= 1e-10f) & (dst >= 0.0f) & (u >= 0.0f) & (v >= 0.0f) & (w >= 0.0f);
-        const bool better = ok & (q.isShadow | (dst < q.bestT));
+        // (for a shadow query only `occluded` below counts; what it keeps as its best hit is not read)
+        const bool better = ok & (dst < q.bestT);
         q.bestT = better ? dst : q.bestT;
         q.bestU = better ? u : q.bestU;
         q.bestV = better ? v : q.bestV;
         q.bestPrim = better ? (int)q.leafPos : q.bestPrim;
         q.leafPos++;
-        finished = q.isShadow && ok;  // occluded
+        finished = q.isShadow & ok;  // occluded
     }
     if (pop) stackPop<STRIDE, LDS_DEPTH>(q, stack, deep);  // both children missed: next sub-tree off the stack
     if (q.cur < 0 && q.leafPos == q.leafEnd) {  // park the leaf `cur` refers to, walk on
@@ -230,7 +235,7 @@ PT_DEV bool queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc,
         q.leafEnd = q.leafPos + (bits & 7u) + 1u;
         stackPop<STRIDE, LDS_DEPTH>(q, stack, deep);
     }
-    return finished || (q.cur == 0 && q.leafPos == q.leafEnd);
+    return finished ? kQueryOccluded : ((q.cur == 0 && q.leafPos == q.leafEnd) ? kQueryDone : kQueryGoesOn);
 }
 
 // ------------------------------------------------------------------------------ path logic
@@ -686,9 +691,10 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
                 prof[5] += (unsigned)__popcll(tri);
             }
             if (mode == kModeTrav) {
-                if (queryStep<COUNT, kMegaThreads, (DEEP > 0 ? STACK : 0)>(S, q, stack, sc, deepStack)) {
+                const int state = queryStep<COUNT, kMegaThreads, (DEEP > 0 ? STACK : 0)>(S, q, stack, sc, deepStack);
+                if (state != kQueryGoesOn) {
                     if (q.isShadow) {
-                        if (q.bestPrim < 0) ps.radiance = ps.radiance + pending;  // unoccluded
+                        if (state != kQueryOccluded) ps.radiance = ps.radiance + pending;
                         if (hasExt) {
                             nRays++;
                             if (COUNT) atomicAdd(&s_depth[ps.bounce < 31u ? ps.bounce : 31u], 1u);
@@ -942,14 +948,16 @@ __global__ __launch_bounds__(kBlockThreads) void traverseKernel(DevParams P, Dev
 
         bool toShade = false;
         unsigned shadeSlot = 0;
-        if (busy && queryStep<COUNT>(S, q, stack, sc)) {
+        const int state = busy ? queryStep<COUNT>(S, q, stack, sc) : (int)kQueryGoesOn;
+        if (state != kQueryGoesOn) {
             const unsigned slot = entry & kEntrySlotMask;
+            const bool unoccluded = state != kQueryOccluded;
             busy = false;
             if (q.isShadow) {
                 const bool last = (entry & kEntryLast) != 0u;
-                if (q.bestPrim < 0 || last) {
+                if (unoccluded || last) {
                     float4 r = W.radRng[slot];
-                    if (q.bestPrim < 0) {  // unoccluded: the pending contribution counts
+                    if (unoccluded) {  // the pending contribution counts
                         const float4 pc = W.pend[slot];
                         r.x = r.x + pc.x;
                         r.y = r.y + pc.y;
