@@ -105,13 +105,11 @@ PT_DEV void beginQuery(Query& q, int rootRef, v3 ro, v3 rd, v3 inv, bool isShado
     q.rd = rd;
     q.inv = inv;
     q.bestT = kFltMax;
-    q.bestU = 0.0f;
-    q.bestV = 0.0f;
-    q.bestPrim = -1;
+    q.bestPrim = -1;  // (bestU and bestV are read only once bestPrim says there is a hit)
     q.sp = 0;
     q.top = 0;
     q.cur = rootRef;
-    q.leafPos = q.leafEnd = 0;
+    q.leafPos = q.leafEnd;  // no leaf parked, whatever the previous query left
     q.isShadow = isShadow;
 }
 PT_DEV void beginQuery(Query& q, int rootRef, v3 ro, v3 rd, bool isShadow) { beginQuery(q, rootRef, ro, rd, reciprocal3(rd), isShadow); }
