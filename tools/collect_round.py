@@ -22,7 +22,7 @@ names = {"c2": "c2_dragonglass_1080p", "c1": "c1_bunnyclearcoat_512", "c3": "c3_
 for k, n in names.items():
     line = open(os.path.join(src, f"bench_{k}.out")).read().strip().splitlines()[-1]
     json.dump(json.loads(line), open(os.path.join(dst, f"{prefix}_bench_{n}.json"), "w"), indent=1)
-for k in ("config_table_host", "config_table_device", "occupancy"):
+for k in ("config_table_host", "config_table_device", "config_table_full-sweep", "occupancy"):
     text = "\n".join(l for l in open(os.path.join(src, k + ".out")).read().splitlines() if "amdgpu.ids" not in l)
     open(os.path.join(dst, f"{prefix}_{k}.txt"), "w").write(text + "\n")
 py = sys.executable
