@@ -407,6 +407,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "level": "L2 + Infinity Cache (scene cache resident)" if cache_resident else "HBM (scene exceeds the 256 MB Infinity Cache)",
+                "note": ("achieved / frac count ALGORITHMIC bytes against the HBM peak; on a cache-resident scene the L1 and L2 serve them "
+                         "(frac can exceed 1): frac_l2 rates them against the L2s, traffic / fabric_gbps are the bytes measured leaving "
+                         "the L2s, valu_busy / lane_utilisation say what bounds the kernel"),
                 "frac_l2": achieved / L2_PEAK_GBS,
                 "fabric_gbps": (traffic / avg_kernel_s / 1e9) if traffic else None,
                 "fabric_frac": ((traffic / avg_kernel_s / 1e9) / (MALL_GATHER_GBS if cache_resident else HBM_PEAK_GBS)) if traffic else None,

@@ -534,6 +534,28 @@ def _chain_tree(levels):
     return nodes.view(np.float32), prims
 
 
+def test_four_wave_kernel_and_scheduler_thresholds_give_the_same_image():
+    """The 4-waves-per-SIMD build of the megakernel (A/B variant) and other phase thresholds change the
+    schedule, not a bit of the result."""
+    o, g = _pair("TorusMixed", 120, 72)
+    p = R.default_params(120, 72)
+    p.max_bounces = 6
+    images = {}
+    for name, tuning in {"default": {}, "four-waves": dict(waves_per_simd=4), "thresholds": dict(trav_exit=8, hit_min=48),
+                         "eager": dict(trav_exit=64, hit_min=1)}.items():
+        g.set_tuning(waves_per_simd=0, trav_exit=32, hit_min=16)
+        g.set_tuning(**tuning)
+        g.set_params(p)
+        g.clear()
+        g.dispatch(1, 5, 1)
+        images[name] = [g.read_image(k) for k in range(3)]
+    cpu = o.render(p, 120, 72, 1, 5, 1)
+    _assert_images_equal(images["default"], cpu[:3], cpu[3], "TorusMixed 120x72 5spp 6 bounces")
+    for name in ("four-waves", "thresholds", "eager"):
+        for k in range(3):
+            assert images[name][k].tobytes() == images["default"][k].tobytes(), (name, k)
+
+
 @PIPELINES
 def test_traversal_stack_beyond_32_entries(pipeline):
     """Trees deeper than 32 levels keep 32 stack entries in LDS and the rest in private memory.  A chain
