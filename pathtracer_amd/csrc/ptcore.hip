@@ -485,11 +485,12 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
         const size_t tiles = (size_t)P.tilesX * P.tilesY;
         if (frameCount > 65535u) return fail(PT_ERR_INVALID, "a megakernel launch takes at most 65535 frames");
         // Splitting costs a little (every block ends in a tail where its lanes run dry), so the cap is
-        // the lower bound itself, or half of it for images with no more tiles than wave slots (swept at
-        // 512 x 512, 720p and 1080p with 16 and 64 frames per launch), unless set by hand.
-        const unsigned split = c->tileSplit >= 0 ? (unsigned)c->tileSplit : (tiles <= c->waveSlots ? 2u : 1u);
-        // (waveSlots counts four waves per SIMD; the three-wave variant holds three quarters of that, which
-        // only makes the cap a little finer)
+        // the lower bound itself, or half of it for images with at most one and a half tiles per wave slot
+        // (swept at 256 x 256, 512 x 512, 800 x 600, 720p and 1080p with 16 and 64 frames per launch: a finer
+        // cap than a half loses everywhere but at 512 x 512 x 64, where a quarter gains 2 %), unless set by hand.
+        // waves the kernel variant in use keeps resident (waveSlots counts four per SIMD and sizes the block list)
+        const uint32_t slots = c->wavesPerSimd != 4 ? c->waveSlots / 4u * 3u : c->waveSlots;
+        const unsigned split = c->tileSplit >= 0 ? (unsigned)c->tileSplit : (tiles <= slots + slots / 2u ? 2u : 1u);
         const size_t capacity = tiles + (size_t)split * c->waveSlots;
         if (c->tileCostTiles != tiles || c->blockCapacity != capacity) {
             for (DeviceBuffer* b : {&c->dTileCost, &c->dTileParts, &c->dTileKey, &c->dTileKeySorted, &c->dTileIds, &c->dTileOrder,
@@ -526,7 +527,7 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
             const unsigned maxParts = split == 0 ? 1u : std::max(1u, std::min(255u, frameCount / 4u));
             const unsigned tb = 256, tg = (unsigned)((tiles + tb - 1) / tb);
             hipLaunchKernelGGL(planPartsKernel, dim3(1), dim3(1024), 0, c->stream, (const unsigned*)c->dTileCost.ptr, (unsigned)tiles,
-                               c->waveSlots, std::max(1u, split), maxParts, (unsigned*)c->dTileParts.ptr,
+                               slots, std::max(1u, split), maxParts, (unsigned*)c->dTileParts.ptr,
                                (unsigned*)c->dTileKey.ptr);
             HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(c->dTileSortTemp.ptr, c->tileSortBytes, (const uint32_t*)c->dTileKey.ptr,
                                                                  (uint32_t*)c->dTileKeySorted.ptr, (const uint32_t*)c->dTileIds.ptr,
