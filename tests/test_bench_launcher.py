@@ -42,3 +42,24 @@ def test_more_gpus_than_devices_fails():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4096"], capture_output=True, text=True,
                        timeout=300, env=env)
     assert r.returncode != 0 and "GPU(s) visible" in r.stderr
+
+
+def test_pmc_summary_is_made_of_the_committed_counters_and_found_by_launch_shape(tmp_path):
+    """tools/make_pmc_summary.py on the committed rocprofv3 counter summary of the benchmark launch, and
+    bench.py's lookup of the result by launch shape."""
+    import argparse
+    out = tmp_path / "pmc_summary.json"
+    shape = "scene=dragonglass width=1920 height=1080 spp_per_step=64 max_bounces=8 subdivide=1 bvh=host copies=1".split()
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_pmc_summary.py"), os.path.join("profiles", "r02_c2_pmc.json"),
+                    str(out)] + shape, check=True, cwd=ROOT, capture_output=True)
+    t = json.loads(out.read_text())
+    assert 0.5 < t["valu_busy"] <= 1.0 and 0.2 < t["lane_utilisation"] < 1.0 and 2.0 < t["waves_per_simd"] <= 3.0
+    assert t["bytes_per_launch"] == (2.0 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0 and t["bound"] == "valu-issue"
+    committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
+    assert {k: committed[k] for k in ("scene", "width", "height", "spp_per_step", "max_bounces", "subdivide", "bvh", "copies")} == \
+        {k: t[k] for k in ("scene", "width", "height", "spp_per_step", "max_bounces", "subdivide", "bvh", "copies")}
+    sys.path.insert(0, ROOT)
+    import bench
+    args = argparse.Namespace(scene="dragonglass", bounces=8, subdivide=1, bvh="host", copies=1)
+    assert bench.pmc_summary(args, 1920, 1080, 64)["bytes_per_launch"] == committed["bytes_per_launch"]
+    assert bench.pmc_summary(args, 1280, 720, 64) is None  # another launch shape: the counters do not apply
