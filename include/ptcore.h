@@ -335,8 +335,8 @@ int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, 
  * its samples spread over several blocks; 0 = one block per tile; -1 (default) = 2 for images with no
  * more tiles than resident waves, else 1;
  * 8: budget of the megakernel's sample buffer in MiB (48 bytes per sample and pixel; a dispatch is cut
- * into launches that fit; default 8192); 9: trees deeper than 32 levels keep their whole traversal stack
- * in LDS (1) instead of 32 entries there and the rest in lane-private memory (0, the default); 10: device
+ * into launches that fit; default 8192); 9: megakernel run by a grid of resident waves that pull the work
+ * items off a counter (1, the default) or by one block per work item (0); 10: device
  * BVH builder: clusters searched on either side per round (default 32; 0 = Morton radix tree instead);
  * 11: megakernel variant compiled for 3 or 4 resident waves per SIMD (default 0: 3). */
 int pt_debug_set_tuning(pt_ctx* ctx, int key, int value);

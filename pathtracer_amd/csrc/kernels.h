@@ -515,7 +515,9 @@ __global__ void fillBlocksKernel(const unsigned* __restrict__ order, const unsig
 
 // STACK entries of traversal stack per lane in LDS, DEEP more in private memory (0: none); compiled
 // for WAVES resident waves per SIMD (4: 128 VGPRs, 3: 168 VGPRs and a quarter of the spills).
-template <int STACK, int DEEP, bool COUNT, int WAVES = PT_WAVES_PER_SIMD>
+// PULL: the grid is as many waves as the chip keeps resident and every wave takes work items off a
+// global counter until none is left; else one block per item.
+template <int STACK, int DEEP, bool COUNT, int WAVES = PT_WAVES_PER_SIMD, bool PULL = true>
 __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P, DevScene S, Images img, DevCounters* counters)
 {
     static_assert(kMegaThreads == 64, "one wave per block: the sample pool below is wave-wide");
@@ -528,46 +530,71 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
     int* stack = s_stack + lane;
     stack[0] = 0;  // row 0 of the stack column: "no entry"
 
-    // Consecutive blocks go to different XCDs, so any block -> tile map that does not cluster
-    // expensive tiles on one XCD keeps the eight of them equally loaded: row-major order without
-    // cost information; with it, the block list the planning kernels below made from the previous
-    // launch's per-tile cost: costliest block first, an expensive tile's samples spread over several
-    // blocks so that no single wave carries the launch's critical path.
-    unsigned tile = blockIdx.x, kBegin = 0, kCount = P.frameCount;
-    if (P.blockList) {
-        // a block past the end of the list gets an empty sample range and falls through the loop below
-        const bool used = blockIdx.x < *P.blockCount;
-        const unsigned w0 = used ? P.blockList[2u * blockIdx.x] : 0u, w1 = used ? P.blockList[2u * blockIdx.x + 1u] : 0u;
-        tile = __builtin_amdgcn_readfirstlane(w0);
-        kBegin = __builtin_amdgcn_readfirstlane(w1 >> 16);
-        kCount = __builtin_amdgcn_readfirstlane(w1 & 0xffffu);
-    }
-    const unsigned tileX = tile % P.tilesX, tileY = tile / P.tilesX;
-
-    // The wave owns its (pixel, sample) pairs as one pool, handed out in sample-major order:
-    // a lane that finishes a path takes the next pair, whichever pixel it belongs to, so no lane
-    // idles while the tile has work, and an expensive pixel's samples are traced by many lanes at
-    // once.  Finished samples are not accumulated here (the running mean of a pixel must take its
-    // samples in FrameCount order): they go to the sample buffer, one record per (sample, pixel),
-    // and resolveKernel folds them into the images in order afterwards.
-    const bool inside = tileX * kMegaTile + (lane & 7u) < P.width && tileY * kMegaTile + (lane >> 3) < P.height;
-    const unsigned long long insideMask = __ballot(inside);
-    const unsigned nInside = (unsigned)__popcll(insideMask);
-    if (inside) s_pixel[laneRank(insideMask)] = lane;
-    __syncthreads();
-    const unsigned poolSize = nInside * kCount;
-    unsigned poolNext = 0;  // wave-uniform
+    // Work items.  An item is a tile's (pixel, sample) pairs for a range of the launch's samples: the
+    // whole range, tile after tile, without cost information; with it, the entries of the list the
+    // planning kernels made from the previous launch's per-tile cost: costliest first, an expensive
+    // tile's samples spread over several entries.  Either every block takes the item of its index, or
+    // (PULL) a wave takes the next item off a global counter whenever its lanes run out of samples:
+    // lanes then go straight on from one item to the next, where a wave per item ends every item in a
+    // tail of idle lanes -- and a launch of few samples per pixel is nothing but tails.  Consecutive
+    // waves start on different XCDs, so the eight of them are equally loaded either way.
+    //
+    // Within an item the pairs form a pool handed out in sample-major order: a lane that finishes a path
+    // takes the next pair, whichever pixel it belongs to, so an expensive pixel's samples are traced by
+    // many lanes at once.  Finished samples are not accumulated here (the running mean of a pixel must
+    // take its samples in FrameCount order): they go to the sample buffer, one record per (sample,
+    // pixel), and resolveKernel folds them into the images in order afterwards.
+    const unsigned itemCount = P.blockList ? *P.blockCount : P.tilesX * P.tilesY;
+    unsigned tile = 0, tileOrigin = 0, kBegin = 0, nInside = 0;  // wave-uniform: the item the lanes are fed from
+    unsigned poolNext = 0, poolSize = 0;
+    bool haveItem = false;
+    unsigned itemStart = (unsigned)wall_clock64();  // (differences of the low word: an item lives far less than its 43 s period)
+    // Makes item `idx` the one the lanes are fed from; all lanes call it together.
+    auto takeItem = [&](unsigned idx) {
+        unsigned kCount = P.frameCount;
+        tile = idx;
+        kBegin = 0;
+        if (P.blockList) {
+            tile = __builtin_amdgcn_readfirstlane(P.blockList[2u * idx]);
+            const unsigned w1 = __builtin_amdgcn_readfirstlane(P.blockList[2u * idx + 1u]);
+            kBegin = w1 >> 16;
+            kCount = w1 & 0xffffu;
+        }
+        const unsigned tileX = tile % P.tilesX, tileY = tile / P.tilesX;
+        tileOrigin = (tileX * kMegaTile) | ((tileY * kMegaTile) << 16);
+        const bool inside = tileX * kMegaTile + (lane & 7u) < P.width && tileY * kMegaTile + (lane >> 3) < P.height;
+        const unsigned long long insideMask = __ballot(inside);
+        nInside = (unsigned)__popcll(insideMask);
+        __syncthreads();  // the previous item's table is no longer read
+        if (inside) s_pixel[laneRank(insideMask)] = lane;
+        __syncthreads();
+        poolNext = 0;
+        poolSize = nInside * kCount;
+        haveItem = true;
+    };
+    // Books the ticks since the item was taken on its tile (the plan of the next launch is made from these sums).
+    auto bookItem = [&]() {
+        const unsigned now = (unsigned)wall_clock64();
+        if (haveItem && lane == 0) {
+            const unsigned lived = now - itemStart;
+            atomicAdd(&P.tileCost[tile], lived > 0x0fffffffu ? 0x0fffffffu : lived);
+        }
+        itemStart = now;
+        haveItem = false;
+    };
+    if (!PULL && blockIdx.x < itemCount) takeItem(blockIdx.x);  // (a block past the end of the list has no item)
 
     unsigned nRays = 0, nShadow = 0, nHits = 0, nSamples = 0;
     StepCounters sc{0u, 0u, 0u};
 
     PathState ps{};
     ps.k = 0;
-    unsigned pixel = 0;  // which pixel of the tile (0..63, row-major) the lane's current sample belongs to
+    unsigned pixel = 0;  // the lane's current sample: x | y << 16 of its pixel in the image
     int mode = kModeNew;
     Query q{};
     v3 extDir = splat(0.0f);   // direction of the extension ray waiting behind a shadow ray ...
-    v3 extInv = splat(0.0f);   // ... and its reciprocal: the divisions are done in the hit block, not at the restart inside the traversal loop
+    v3 extInv = splat(0.0f);   // ... and, without PULL, its reciprocal: the divisions are then done in the hit block, not at the restart
+                               // inside the traversal loop (with PULL the three registers cost more than the divisions)
     v3 pending = splat(0.0f);  // NEE contribution, added if the shadow ray is unoccluded
     bool hasExt = false;
 
@@ -612,7 +639,7 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
                 pending = br.pending;
                 hasExt = br.hasExt;
                 extDir = br.extDir;
-                extInv = reciprocal3(br.extDir);
+                if (!PULL) extInv = reciprocal3(br.extDir);
                 beginQuery(q, P.rootRef, br.origin, br.shadowDir, true);
                 mode = kModeTrav;
             } else if (br.hasExt) {
@@ -631,38 +658,53 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
         // a finished sample goes to its record of the sample buffer
         if (COUNT) prof[10] += (unsigned)__popcll(__ballot(mode == kModeFinish));
         if (mode == kModeFinish) {
-            const unsigned px = tileX * kMegaTile + (pixel & 7u), py = tileY * kMegaTile + (pixel >> 3);
+            const unsigned px = pixel & 0xffffu, py = pixel >> 16;
             float4* rec = reinterpret_cast<float4*>(P.samples) + ((size_t)ps.k * P.pixels + ((size_t)py * P.width + px)) * 3u;
             rec[0] = make_float4(ps.radiance.x, ps.radiance.y, ps.radiance.z, 0.0f);
             rec[1] = make_float4(ps.albedoRes.x, ps.albedoRes.y, ps.albedoRes.z, 0.0f);
             rec[2] = make_float4(ps.normalRes.x, ps.normalRes.y, ps.normalRes.z, 0.0f);
             mode = kModeNew;
         }
-        // lanes without a sample take the next (pixel, sample) pairs of the pool
-        const unsigned long long wantMask = __ballot(mode == kModeNew);
-        if (wantMask != 0ull) {
-            const unsigned item = poolNext + laneRank(wantMask);
-            if (mode == kModeNew) {
-                if (item < poolSize) {
-                    const unsigned slot = nInside == 64u ? (item & 63u) : item % nInside;
-                    ps.k = kBegin + (nInside == 64u ? (item >> 6) : item / nInside);
-                    pixel = s_pixel[slot];
-                    v3 ro, rd;
-                    startSample(P, tileX * kMegaTile + (pixel & 7u), tileY * kMegaTile + (pixel >> 3), ps, ro, rd);
-                    hasExt = false;
-                    nSamples++;
-                    nRays++;
-                    if (COUNT) atomicAdd(&s_depth[0], 1u);
-                    beginQuery(q, P.rootRef, ro, rd, false);
-                    mode = kModeTrav;
-                } else {
-                    mode = kModeDone;
+        // lanes without a sample take the next (pixel, sample) pairs of the pool, and of the next item
+        // when this one runs out
+        unsigned long long startedMask = 0ull;
+        for (;;) {
+            const unsigned long long wantMask = __ballot(mode == kModeNew);
+            if (wantMask == 0ull) break;
+            if (poolNext == poolSize) {
+                unsigned idx = itemCount;
+                if (PULL) {
+                    bookItem();
+                    if (lane == 0) idx = atomicAdd(P.workNext, 1u);  // (goes on counting when the items are gone: once per wave)
+                    idx = __builtin_amdgcn_readfirstlane(idx);
                 }
+                if (idx >= itemCount) {
+                    if (mode == kModeNew) mode = kModeDone;
+                    break;
+                }
+                takeItem(idx);
+                if (poolSize == 0u) continue;  // an empty item
+            }
+            const unsigned item = poolNext + laneRank(wantMask);
+            if (mode == kModeNew && item < poolSize) {
+                const unsigned slot = nInside == 64u ? (item & 63u) : item % nInside;
+                ps.k = kBegin + (nInside == 64u ? (item >> 6) : item / nInside);
+                const unsigned inTile = s_pixel[slot];
+                pixel = tileOrigin + ((inTile & 7u) | ((inTile >> 3) << 16));
+                v3 ro, rd;
+                startSample(P, pixel & 0xffffu, pixel >> 16, ps, ro, rd);
+                hasExt = false;
+                nSamples++;
+                nRays++;
+                if (COUNT) atomicAdd(&s_depth[0], 1u);
+                beginQuery(q, P.rootRef, ro, rd, false);
+                mode = kModeTrav;
             }
             const unsigned want = (unsigned)__popcll(wantMask);
             poolNext = poolSize - poolNext < want ? poolSize : poolNext + want;
+            if (COUNT) startedMask |= wantMask;
         }
-        if (COUNT) prof[11] += (unsigned)__popcll(wantMask & __ballot(mode == kModeTrav));
+        if (COUNT) prof[11] += (unsigned)__popcll(startedMask & __ballot(mode == kModeTrav));
         if (__ballot(mode == kModeTrav || mode == kModeShade) == 0ull) break;
         // Leave the traversal phase once fewer than `threshold` lanes are traversing; lanes that
         // are done for good or wait for the hit block do not count against the wave.
@@ -697,7 +739,8 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
                             nRays++;
                             if (COUNT) atomicAdd(&s_depth[ps.bounce < 31u ? ps.bounce : 31u], 1u);
                             hasExt = false;
-                            beginQuery(q, P.rootRef, q.ro, extDir, extInv, false);
+                            if (PULL) beginQuery(q, P.rootRef, q.ro, extDir, false);
+                            else beginQuery(q, P.rootRef, q.ro, extDir, extInv, false);
                         } else {
                             mode = kModeFinish;
                         }
@@ -716,10 +759,8 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
 
     // counters: wave-level reduction, one atomic per wave and counter
     const unsigned sRays = waveSum(nRays), sShadow = waveSum(nShadow), sHits = waveSum(nHits), sSamples = waveSum(nSamples);
-    if (kMegaThreads == 64 && lane == 0) {
-        const unsigned long long lived = wall_clock64() - waveStart;
-        if (kCount) atomicAdd(&P.tileCost[tile], lived > 0x0fffffffull ? 0x0fffffffu : (unsigned)lived);  // summed over the tile's blocks
-    }
+    const unsigned nSamplesWave = __builtin_amdgcn_readfirstlane(sSamples);
+    bookItem();  // the last item's share of the wave's life
     if (lane == 0) {
         atomicAdd(&counters->raysClosest, (unsigned long long)sRays);
         atomicAdd(&counters->raysAny, (unsigned long long)sShadow);
@@ -735,7 +776,7 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
             for (int i = 0; i < 16; i++) atomicAdd(&counters->profile[i], prof[i]);
             for (int i = 0; i < 32; i++)
                 if (s_depth[i]) atomicAdd(&counters->depthRays[i], (unsigned long long)s_depth[i]);
-            if (P.waveTimes && kCount) {
+            if (P.waveTimes && nSamplesWave) {
                 P.waveTimes[2 * (size_t)blockIdx.x] = waveStart;
                 P.waveTimes[2 * (size_t)blockIdx.x + 1] = wall_clock64();
             }

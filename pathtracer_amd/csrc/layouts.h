@@ -158,9 +158,10 @@ struct DevParams {
     int32_t rootRef;
     uint32_t tilesX, tilesY;
     uint32_t travExitNum;  // megakernel: leave the traversal phase below this many 64ths of the live lanes
-    const unsigned int* blockList;  // megakernel: per block {tile, first sample << 16 | samples}, costliest block first (null: block = tile)
-    const unsigned int* blockCount; // megakernel: entries of blockList in use (blocks past it exit at once)
-    unsigned int* tileCost;         // megakernel: per tile, ticks its wave lived (input of the next launch's order)
+    const unsigned int* blockList;  // megakernel: work items {tile, first sample << 16 | samples}, costliest first (null: item = tile, all samples)
+    const unsigned int* blockCount; // megakernel: entries of blockList in use
+    unsigned int* tileCost;         // megakernel: per tile, ticks waves spent on its items (input of the next launch's order)
+    unsigned int* workNext;         // megakernel: next work item to hand out (zeroed before the launch)
     float* samples;                 // megakernel: finished samples, 3 x float4 per (sample, pixel), sample-major
     unsigned long long pixels;      // width * height
     unsigned long long* waveTimes;  // counting build: per tile, wall-clock ticks at wave start and end (or null)

@@ -130,7 +130,7 @@ struct pt_ctx {
     int wavesPerSimd = 0;      // megakernel variant: 3 or 4 waves per SIMD (0: the default, 3)
     bool rebuildOnUpload = false;  // pt_upload_nodes' tree is replaced by the device builder's over the same primitives
     int plocRadius = 32;  // device BVH builder: neighbours searched on either side per clustering round (0: Morton radix tree)
-    bool deepStackInLds = false;  // trees deeper than 32 levels: whole stack in LDS (12/16 KB per wave)
+    bool pullItems = true;  // megakernel: resident waves pull the work items (else one block per item)
     size_t waveTimeCount = 0;
     // geometry built on the device (pt_build_bvh_device): the tree in the reference's layouts, kept for
     // pt_download_bvh; dNodes / dTriangles / dShading are filled by the builder itself
@@ -429,32 +429,37 @@ void fillLaunchBlocks(const pt_ctx* c, uint32_t frameFirst, uint32_t frameCount,
     P.refillMin = c->refillMin;
     P.hitMinNum = c->hitMinNum;
     P.waveTimes = nullptr;
+    P.workNext = nullptr;
 }
 
-// Launches the trace kernel variant that fits the tree in use.
-void launchTrace(const pt_ctx* c, const DevParams& P, const DevScene& S, const Images& img, DevCounters* ctr, dim3 grid, bool counted)
+// Launches the trace kernel variant that fits the tree in use.  `pull`: a grid of resident waves that take
+// the work items off a counter; else one block per item.
+void launchTrace(const pt_ctx* c, const DevParams& P, const DevScene& S, const Images& img, DevCounters* ctr, dim3 grid, bool counted,
+                 bool pull)
 {
     const dim3 block(kMegaThreads);
     // Trees up to 32 levels deep keep the whole traversal stack in LDS (8 KB per wave).  Deeper
-    // ones keep 32 entries there and the rest in private memory (3 % slower than the all-LDS kernel
-    // on a 5 M-triangle scene whose tree is 34 deep; a 40-entry LDS stack, 15 waves per CU, costs
-    // 6 %, a 48-entry one 13 %), or (deepStackInLds, for A/B) get a 12 or 16 KB LDS stack.
-    const int stackClass = c->maxDepth <= 32 ? 0 : (!c->deepStackInLds ? 3 : (c->maxDepth <= 48 ? 1 : 2));
-    // Three waves per SIMD (168 VGPRs, nothing spilled) unless four are asked for (128 VGPRs, 66 values
-    // spilled in the shading blocks): three are 2 % faster on the reference's tree of the benchmark scene
+    // ones keep 32 entries there and the rest in private memory (3 % slower than an all-LDS kernel
+    // on a 5 M-triangle scene whose tree is 34 deep; a 40-entry LDS stack costs 6 %, a 48-entry one 13 %).
+    const bool deep = c->maxDepth > 32;
+    // Three waves per SIMD (168 VGPRs, next to nothing spilled) unless four are asked for (128 VGPRs, some 70
+    // values spilled in the shading blocks): three are 2 % faster on the reference's tree of the benchmark scene
     // and 10 % faster on the trees of this library's own builders, where shading weighs more.
     const bool three = c->wavesPerSimd != 4;
-#define PT_LAUNCH_TRACE(COUNTED)                                                                                                 \
-    do {                                                                                                                         \
-        if (stackClass == 3 && three) hipLaunchKernelGGL((renderKernel<32, 32, COUNTED, 3>), grid, block, 0, c->stream, P, S, img, ctr); \
-        else if (stackClass == 3) hipLaunchKernelGGL((renderKernel<32, 32, COUNTED>), grid, block, 0, c->stream, P, S, img, ctr);        \
-        else if (stackClass == 2) hipLaunchKernelGGL((renderKernel<64, 0, COUNTED>), grid, block, 0, c->stream, P, S, img, ctr);         \
-        else if (stackClass == 1) hipLaunchKernelGGL((renderKernel<48, 0, COUNTED>), grid, block, 0, c->stream, P, S, img, ctr);         \
-        else if (three) hipLaunchKernelGGL((renderKernel<32, 0, COUNTED, 3>), grid, block, 0, c->stream, P, S, img, ctr);                \
-        else hipLaunchKernelGGL((renderKernel<32, 0, COUNTED>), grid, block, 0, c->stream, P, S, img, ctr);                              \
+#define PT_LAUNCH_TRACE(STACK_DEEP, COUNTED, WAVES, PULL) \
+    hipLaunchKernelGGL((renderKernel<32, STACK_DEEP, COUNTED, WAVES, PULL>), grid, block, 0, c->stream, P, S, img, ctr)
+#define PT_LAUNCH_TRACE_4(STACK_DEEP, COUNTED)                            \
+    do {                                                                  \
+        if (three && pull) PT_LAUNCH_TRACE(STACK_DEEP, COUNTED, 3, true); \
+        else if (three) PT_LAUNCH_TRACE(STACK_DEEP, COUNTED, 3, false);   \
+        else if (pull) PT_LAUNCH_TRACE(STACK_DEEP, COUNTED, 4, true);     \
+        else PT_LAUNCH_TRACE(STACK_DEEP, COUNTED, 4, false);              \
     } while (0)
-    if (counted) PT_LAUNCH_TRACE(true);
-    else PT_LAUNCH_TRACE(false);
+    if (deep && counted) PT_LAUNCH_TRACE_4(32, true);
+    else if (deep) PT_LAUNCH_TRACE_4(32, false);
+    else if (counted) PT_LAUNCH_TRACE_4(0, true);
+    else PT_LAUNCH_TRACE_4(0, false);
+#undef PT_LAUNCH_TRACE_4
 #undef PT_LAUNCH_TRACE
 }
 
@@ -484,18 +489,18 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
         // critical path (small images, a few expensive tiles in a cheap frame).
         const size_t tiles = (size_t)P.tilesX * P.tilesY;
         if (frameCount > 65535u) return fail(PT_ERR_INVALID, "a megakernel launch takes at most 65535 frames");
-        // Splitting costs a little (every block ends in a tail where its lanes run dry), so the cap is
-        // the lower bound itself, or half of it for images with at most one and a half tiles per wave slot
-        // (swept at 256 x 256, 512 x 512, 800 x 600, 720p and 1080p with 16 and 64 frames per launch: a finer
-        // cap than a half loses everywhere but at 512 x 512 x 64, where a quarter gains 2 %), unless set by hand.
-        // waves the kernel variant in use keeps resident (waveSlots counts four per SIMD and sizes the block list)
+        // waves the kernel variant in use keeps resident (waveSlots counts four per SIMD and sizes the item list)
         const uint32_t slots = c->wavesPerSimd != 4 ? c->waveSlots / 4u * 3u : c->waveSlots;
-        const unsigned split = c->tileSplit >= 0 ? (unsigned)c->tileSplit : (tiles <= slots + slots / 2u ? 2u : 1u);
+        // The cap on an item's cost is 1/split of the launch's lower bound.  Waves that pull their items lose nothing
+        // at an item's end, so the cap can be fine: swept over 1, 2, 4 ... 64 with 64 frames per launch, a 32nd is 11 %
+        // faster than a half at 512 x 512 and 3 % at 720p, makes no difference at 1080p, and is 4 % slower than an
+        // eighth at 256 x 256, where there are fewer tiles than waves.  Unless set by hand.
+        const unsigned split = c->tileSplit >= 0 ? (unsigned)c->tileSplit : (tiles < slots ? 8u : 32u);
         const size_t capacity = tiles + (size_t)split * c->waveSlots;
         if (c->tileCostTiles != tiles || c->blockCapacity != capacity) {
             for (DeviceBuffer* b : {&c->dTileCost, &c->dTileParts, &c->dTileKey, &c->dTileKeySorted, &c->dTileIds, &c->dTileOrder,
                                     &c->dPartsInOrder, &c->dBlockStart})
-                HIP_TRY(b->ensure(tiles * 4));
+                HIP_TRY(b->ensure((tiles + 1) * 4));  // (the cost words are followed by the launch's work counter)
             HIP_TRY(c->dBlockList.ensure(capacity * 8));
             HIP_TRY(c->dBlockCount.ensure(4));
             std::vector<uint32_t> ids(tiles);
@@ -519,6 +524,7 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
         P.samples = (float*)c->dSamples.ptr;
         P.pixels = (unsigned long long)c->width * c->height;
         P.tileCost = (unsigned int*)c->dTileCost.ptr;
+        P.workNext = P.tileCost + tiles;
         P.blockList = nullptr;
         P.blockCount = nullptr;
         size_t gridBlocks = tiles;
@@ -542,9 +548,14 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
             HIP_TRY(hipGetLastError());
             P.blockList = (const unsigned int*)c->dBlockList.ptr;
             P.blockCount = (const unsigned int*)c->dBlockCount.ptr;
-            gridBlocks = split == 0 ? tiles : capacity;  // blocks past the list's end find an empty sample range
+            gridBlocks = split == 0 ? tiles : capacity;  // the most items the list can hold (blocks past its end find none)
         }
-        HIP_TRY(hipMemsetAsync(c->dTileCost.ptr, 0, tiles * 4, c->stream));  // blocks add their lifetimes
+        // The items are pulled by a grid of as many waves as the chip keeps resident (a block per item spends the end
+        // of its life with idle lanes, and a launch of few samples per pixel is nothing but such ends: 1080p, benchmark
+        // scene, one sample per pixel 2.5 -> 1.3 ms, 16 samples 12.1 -> 10.8 ms, 64 samples 43.7 -> 41.9 ms).
+        const bool pull = c->pullItems != 0;
+        if (pull) gridBlocks = std::min<size_t>(gridBlocks, slots);
+        HIP_TRY(hipMemsetAsync(c->dTileCost.ptr, 0, (tiles + 1) * 4, c->stream));  // waves add the ticks they spend; work counter
         c->tileCostValid = true;
         if (counted) {
             c->waveTimeCount = gridBlocks;
@@ -554,7 +565,7 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
         }
         const dim3 grid((unsigned)gridBlocks);
         HIP_TRY(hipEventRecord(c->evTrace0, c->stream));
-        launchTrace(c, P, S, img, ctr, grid, counted);
+        launchTrace(c, P, S, img, ctr, grid, counted, pull);
         HIP_TRY(hipEventRecord(c->evTrace1, c->stream));
         hipLaunchKernelGGL(resolveKernel, dim3((unsigned)((P.pixels + 255) / 256)), dim3(256), 0, c->stream, P, img);
         HIP_TRY(hipGetLastError());
@@ -1110,7 +1121,7 @@ int pt_dispatch_static(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint
     if (!base) return fail(PT_ERR_STATE, "no static scratch on this device");
     const size_t pixels = (size_t)c->width * c->height;
     const size_t tiles = (size_t)((c->width + kMegaTile - 1) / kMegaTile) * (size_t)((c->height + kMegaTile - 1) / kMegaTile);
-    const size_t costBytes = (tiles * 4 + 255) / 256 * 256;
+    const size_t costBytes = ((tiles + 1) * 4 + 255) / 256 * 256;  // per-tile cost words and the work counter
     const size_t need = costBytes + (size_t)frameCount * pixels * 48u;
     if (need > kStaticScratchBytes)
         return fail(PT_ERR_INVALID, "pt_dispatch_static: " + std::to_string(frameCount) + " frames of " + std::to_string(c->width) + "x" +
@@ -1121,6 +1132,7 @@ int pt_dispatch_static(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint
     DevScene S;
     fillLaunchBlocks(c, frameFirst, frameCount, frameStride, P, S);
     P.tileCost = (unsigned int*)base;
+    P.workNext = P.tileCost + tiles;
     P.samples = (float*)(base + costBytes);
     P.pixels = pixels;
     P.blockList = nullptr;
@@ -1129,7 +1141,8 @@ int pt_dispatch_static(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint
     Images img{imagePtr(c, 0), imagePtr(c, 1), imagePtr(c, 2)};
     HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(DevCounters), c->stream));
     HIP_TRY(hipMemsetAsync(base, 0, costBytes, c->stream));  // the array keeps the previous call's contents
-    launchTrace(c, P, S, img, ctr, dim3((unsigned)tiles), false);
+    const uint32_t slots = c->wavesPerSimd != 4 ? c->waveSlots / 4u * 3u : c->waveSlots;
+    launchTrace(c, P, S, img, ctr, dim3((unsigned)std::min<size_t>(tiles, slots)), false, true);
     hipLaunchKernelGGL(resolveKernel, dim3((unsigned)((P.pixels + 255) / 256)), dim3(256), 0, c->stream, P, img);
     HIP_TRY(hipGetLastError());
     c->timed = false;  // no events around this launch
@@ -1263,8 +1276,8 @@ int pt_scene_bytes(pt_ctx* c, uint64_t* nodeBytes, uint64_t* triangleBytes, uint
 // 5: megakernel hit-shading threshold in 64ths of the live lanes; 6: launch plan from the previous launch's tile costs on/off;
 // 7: tile split: no megakernel block may cost more than 1/value of the launch's lower bound (0: one block per tile,
 // -1: chosen from the number of tiles per wave slot); 8: sample-buffer budget in MiB (a dispatch is
-// cut into launches whose sample records fit); 9: trees deeper than 32 levels keep their whole traversal
-// stack in LDS (1) instead of 32 entries there and the rest in private memory (0, the default); 10: device BVH
+// cut into launches whose sample records fit); 9: megakernel run by resident waves that pull the
+// work items off a counter (1, the default) or by one block per item (0); 10: device BVH
 // builder: clustering search radius (0 = Morton radix tree); 11: megakernel compiled for 3 or 4 waves per SIMD
 // (0 = the default, 3).
 int pt_debug_set_tuning(pt_ctx* c, int key, int value)
@@ -1304,8 +1317,8 @@ int pt_debug_set_tuning(pt_ctx* c, int key, int value)
         c->tileSplit = value;
         return PT_OK;
     case 9:
-        if (value != 0 && value != 1) return fail(PT_ERR_INVALID, "deep_stack_in_lds must be 0 or 1");
-        c->deepStackInLds = value != 0;
+        if (value != 0 && value != 1) return fail(PT_ERR_INVALID, "pull_items must be 0 or 1");
+        c->pullItems = value != 0;
         return PT_OK;
     case 11:
         if (value != 0 && value != 3 && value != 4) return fail(PT_ERR_INVALID, "waves per SIMD must be 0 (automatic), 3 or 4");

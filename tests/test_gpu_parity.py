@@ -560,7 +560,7 @@ def test_four_wave_kernel_and_scheduler_thresholds_give_the_same_image():
 def test_traversal_stack_beyond_32_entries(pipeline):
     """Trees deeper than 32 levels keep 32 stack entries in LDS and the rest in private memory.  A chain
     tree drives the stack to 40 entries; the image must equal the one traced through the sweep-SAH tree
-    of the same triangles and the one traced with the whole stack in LDS."""
+    of the same triangles, with one block per work item and with waves that pull the items."""
     levels = 40
     nodes40, prims = _chain_tree(levels)
     mats = np.array([scenes.material(albedo=(0.7, 0.6, 0.5), roughness=0.6)], dtype=scenes.MATERIAL_DTYPE)
@@ -568,9 +568,9 @@ def test_traversal_stack_beyond_32_entries(pipeline):
     images = {}
     sorted_prims, sah_nodes = R.build_bvh_sah(prims, 4)
     for name, (n40, p100, tuning) in {
-        "chain": (nodes40, prims, dict(deep_stack_in_lds=0)),
-        "chain-lds": (nodes40, prims, dict(deep_stack_in_lds=1)),
-        "sah": (sah_nodes, sorted_prims, dict(deep_stack_in_lds=0)),
+        "chain": (nodes40, prims, dict(pull_items=0)),
+        "chain-pull": (nodes40, prims, dict(pull_items=1)),
+        "sah": (sah_nodes, sorted_prims, dict()),
     }.items():
         g = R.Renderer(96, 64)
         g.set_tuning(pipeline=pipeline, **tuning)
@@ -586,6 +586,6 @@ def test_traversal_stack_beyond_32_entries(pipeline):
         if name.startswith("chain"):
             assert g.stats().max_stack_depth >= levels, g.stats().max_stack_depth
     for k in range(3):
-        assert images["chain"][k].tobytes() == images["chain-lds"][k].tobytes()
+        assert images["chain"][k].tobytes() == images["chain-pull"][k].tobytes()
         assert images["chain"][k].tobytes() == images["sah"][k].tobytes()
     assert np.any(images["chain"][0][..., :3] > 0)
