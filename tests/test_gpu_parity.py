@@ -535,23 +535,27 @@ def _chain_tree(levels):
 
 
 def test_four_wave_kernel_and_scheduler_thresholds_give_the_same_image():
-    """The 4-waves-per-SIMD build of the megakernel (A/B variant) and other phase thresholds change the
-    schedule, not a bit of the result."""
+    """The 4-waves-per-SIMD build of the megakernel (A/B variant), one block per work item instead of waves
+    that pull the items, and other phase thresholds change the schedule, not a bit of the result."""
     o, g = _pair("TorusMixed", 120, 72)
     p = R.default_params(120, 72)
     p.max_bounces = 6
     images = {}
-    for name, tuning in {"default": {}, "four-waves": dict(waves_per_simd=4), "thresholds": dict(trav_exit=8, hit_min=48),
-                         "eager": dict(trav_exit=64, hit_min=1)}.items():
-        g.set_tuning(waves_per_simd=0, trav_exit=32, hit_min=16)
+    variants = {"default": {}, "four-waves": dict(waves_per_simd=4), "thresholds": dict(trav_exit=8, hit_min=48),
+                "eager": dict(trav_exit=64, hit_min=1), "block-per-item": dict(pull_items=0),
+                "four-waves-block-per-item": dict(waves_per_simd=4, pull_items=0), "unsplit": dict(tile_split=0),
+                "fine-split": dict(tile_split=64)}
+    for name, tuning in variants.items():
+        g.set_tuning(waves_per_simd=0, trav_exit=32, hit_min=16, pull_items=1, tile_split=-1)
         g.set_tuning(**tuning)
         g.set_params(p)
         g.clear()
-        g.dispatch(1, 5, 1)
+        g.dispatch(1, 2, 1)  # (the second dispatch runs from the plan made of the first one's tile costs)
+        g.dispatch(3, 3, 1)
         images[name] = [g.read_image(k) for k in range(3)]
     cpu = o.render(p, 120, 72, 1, 5, 1)
     _assert_images_equal(images["default"], cpu[:3], cpu[3], "TorusMixed 120x72 5spp 6 bounces")
-    for name in ("four-waves", "thresholds", "eager"):
+    for name in variants:
         for k in range(3):
             assert images[name][k].tobytes() == images["default"][k].tobytes(), (name, k)
 

@@ -31,6 +31,8 @@ tuning = dict(item.split("=") for item in sys.argv[2:])
 if tuning:
     g.set_tuning(**{k: int(v) for k, v in tuning.items()})
 g.clear()
+g.dispatch(1, spp, 1)  # (leaves the tile costs the next launch is planned from)
+g.clear()
 g.dispatch(1, spp, 1, counted=True)
 g.synchronize()
 st, pr = g.stats(), g.profile()
@@ -57,4 +59,5 @@ if len(wt):
     edges = np.linspace(0, span, 11)
     conc = [((start < b) & (end > a)).sum() for a, b in zip(edges[:-1], edges[1:])]
     print("  waves alive per tenth of the span:", conc)
+    print("  wave ends, percentiles 1/10/25/50/75/90/99/100 in ms:", " ".join(f"{np.percentile(end, q):.3f}" for q in (1, 10, 25, 50, 75, 90, 99, 100)))
     print(f"  last wave to start began at {start.max():.2f} ms; waves still running at 90% of the span: {(end > 0.9 * span).sum()}")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time of one dispatch of the benchmark workload at 1, 2, 4 ... 64 samples per pixel per dispatch
 (the viewer's call pattern is one sample per dispatch).
-    python tools/spp_scan.py [pull_items]      # 1 (default) or 0
+    python tools/spp_scan.py [pull_items [spp,spp,...]]      # pull_items: 1 (default) or 0
 """
 import os
 import sys
@@ -18,7 +18,7 @@ p = R.default_params(1920, 1080); p.max_bounces = 8; g.set_params(p)
 if len(sys.argv) > 1:
     g.set_tuning(pull_items=int(sys.argv[1]))
 import time
-for spp in (1, 2, 4, 8, 16, 64):
+for spp in ([int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else (1, 2, 4, 8, 16, 64)):
     g.clear(); g.dispatch(1, spp, 1); g.synchronize()
     n = max(4, 64 // spp)
     t0 = time.perf_counter(); rays = 0; f = 1
