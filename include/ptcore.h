@@ -338,7 +338,10 @@ int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, 
  * into launches that fit; default 8192); 9: megakernel run by a grid of resident waves that pull the work
  * items off a counter (1, the default) or by one block per work item (0); 10: device
  * BVH builder: clusters searched on either side per round (default 32; 0 = Morton radix tree instead);
- * 11: megakernel variant compiled for 3 or 4 resident waves per SIMD (default 0: 3). */
+ * 11: megakernel variant compiled for 3 or 4 resident waves per SIMD (default 0: 3); 12: the trace launches
+ * of consecutive pt_dispatch calls may overlap, the next call's waves filling the chip while the last waves of
+ * the call before run dry (1), never do (0), or do for calls of at most 8 frames (-1, the default); calls
+ * overlap on the library's own stream only, never on one set with pt_set_stream. */
 int pt_debug_set_tuning(pt_ctx* ctx, int key, int value);
 
 /* Profiling hook, not part of the drop-in surface (no counterpart in the reference): wave-level

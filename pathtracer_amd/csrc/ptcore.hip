@@ -81,6 +81,7 @@ struct PendingModel {
 // host-side stand-in, not a device address).
 constexpr size_t kStaticScratchBytes = PT_STATIC_SCRATCH_BYTES;
 constexpr int kMaxDevices = 64;
+constexpr int kLaunchLanes = 3;  // dispatch calls whose launches may be in flight together
 void* g_scratchPtr[kMaxDevices] = {};
 
 }  // namespace
@@ -113,19 +114,38 @@ struct pt_ctx {
     // device side
     DeviceBuffer dNodes, dTriangles, dShading, dMaterials, dTextures, dTexels, dSrgbLut, dEnvColorPdf, dEnvSample;
     DeviceBuffer dImages[3];
-    DeviceBuffer dCounters;
+    DeviceBuffer dCounters[kLaunchLanes];  // one set per launch lane (a call's launches may still run when the next calls start)
+    int counterSet = 0;         // the set of the most recent dispatch call: its lane's
     DeviceBuffer dRgbStaging;  // pt_read_image_rgb
     DeviceBuffer dWaveTimes;   // counting dispatches: start / end ticks per wave
-    // launch plan of the megakernel from the ticks each tile's waves lived in the previous launch:
-    // blocks per tile, per-block cost (the sort key), tiles in descending key order, block list
-    DeviceBuffer dTileCost, dTileParts, dTileKey, dTileKeySorted, dTileIds, dTileOrder, dTileSortTemp;
-    DeviceBuffer dPartsInOrder, dBlockStart, dBlockList, dBlockCount, dScanTemp;
-    size_t tileCostTiles = 0, tileSortBytes = 0, scanBytes = 0, blockCapacity = 0;
-    bool tileCostValid = false, tileOrdering = true;
+    // What a megakernel launch owns besides the scene and the images, in several sets.  Dispatch calls of few frames
+    // take the sets in turn and trace on the set's own stream, so that the waves of one call's launch
+    // fill the chip while the last waves of the call before run dry (with one sample per pixel that tail is two
+    // fifths of a launch).  The resolve passes all run on the context's stream, in call order; everything else the
+    // library does is on that stream too and therefore behind every trace launched before it.
+    struct LaunchLane {
+        // launch plan from the ticks each tile's waves lived in the lane's previous launch: items per tile, per-item
+        // cost (the sort key), tiles in descending key order, item list
+        DeviceBuffer dTileCost, dTileParts, dTileKey, dTileKeySorted, dTileIds, dTileOrder, dTileSortTemp;
+        DeviceBuffer dPartsInOrder, dBlockStart, dBlockList, dBlockCount, dScanTemp;
+        size_t tileCostTiles = 0, tileSortBytes = 0, scanBytes = 0, blockCapacity = 0;
+        bool tileCostValid = false;
+        // finished samples of one launch, 48 B per (sample, pixel); resolved into the images after the launch
+        DeviceBuffer dSamples;
+        hipStream_t stream = nullptr;    // traces of overlapping calls
+        hipEvent_t evTraced = nullptr;   // on `stream`, behind the trace kernel
+        hipEvent_t evFree = nullptr;     // on the context's stream, behind the resolve pass that read the lane's samples
+        bool used = false;               // evFree has been recorded
+        uint64_t forkSeen = 0;           // the last evFork `stream` has waited for
+    } lane[kLaunchLanes];
+    int lastLane = 0;
+    int overlap = -1;            // calls overlap: never (0), whenever allowed (1), calls of at most 8 frames (-1)
+    hipEvent_t evFork = nullptr; // on the context's stream, behind the last work other than dispatches that the traces must see
+    uint64_t forkCount = 0;
+    bool forkDirty = true;
+    bool tileOrdering = true;
     int tileSplit = -1;  // no block may cost more than 1/tileSplit of the launch's lower bound (0: never split, -1: by image size)
     uint32_t waveSlots = 4096;  // waves the chip holds at once (CUs x SIMDs x waves per SIMD)
-    // finished samples of one launch, 48 B per (sample, pixel); resolved into the images after the launch
-    DeviceBuffer dSamples;
     uint64_t sampleBudgetBytes = 8ull << 30;
     int wavesPerSimd = 0;      // megakernel variant: 3 or 4 waves per SIMD (0: the default, 3)
     bool rebuildOnUpload = false;  // pt_upload_nodes' tree is replaced by the device builder's over the same primitives
@@ -169,6 +189,11 @@ struct DeviceGuard {
         if (previous >= 0) (void)hipSetDevice(previous);
     }
 };
+
+void forgetTileCosts(pt_ctx* c)
+{
+    for (pt_ctx::LaunchLane& L : c->lane) L.tileCostValid = false;
+}
 
 float4* imagePtr(pt_ctx* c, int which) { return c->bound[which] ? c->bound[which] : (float4*)c->dImages[which].ptr; }
 
@@ -223,6 +248,8 @@ int syncScene(pt_ctx* c)
         c->triangleBytes = tb;
         c->shadingBytes = sb;
         c->geometryDirty = false;
+    c->forkDirty = true;  // (the builder's kernels ran on the context's stream)
+        c->forkDirty = true;
     }
     if (c->texturesDirty) {
         std::vector<DevTexture> table;
@@ -254,6 +281,7 @@ int syncScene(pt_ctx* c)
         HIP_TRY(hipMemcpyAsync(c->dSrgbLut.ptr, lut, sizeof(lut), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->texturesDirty = false;
+        c->forkDirty = true;
         c->materialsDirty = true;  // texture table indices may have moved
     }
     if (c->materialsDirty) {
@@ -268,6 +296,7 @@ int syncScene(pt_ctx* c)
         HIP_TRY(hipMemcpyAsync(c->dMaterials.ptr, packed.data(), packed.size() * sizeof(DevMaterial), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->materialsDirty = false;
+        c->forkDirty = true;
     }
     if (c->envDirty) {
         HIP_TRY(c->dEnvColorPdf.ensure(c->envColorPdf.size() * sizeof(float)));
@@ -276,6 +305,7 @@ int syncScene(pt_ctx* c)
         HIP_TRY(hipMemcpyAsync(c->dEnvSample.ptr, c->envSample.data(), c->envSample.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->envDirty = false;
+        c->forkDirty = true;
     }
     return PT_OK;
 }
@@ -434,8 +464,8 @@ void fillLaunchBlocks(const pt_ctx* c, uint32_t frameFirst, uint32_t frameCount,
 
 // Launches the trace kernel variant that fits the tree in use.  `pull`: a grid of resident waves that take
 // the work items off a counter; else one block per item.
-void launchTrace(const pt_ctx* c, const DevParams& P, const DevScene& S, const Images& img, DevCounters* ctr, dim3 grid, bool counted,
-                 bool pull)
+void launchTrace(const pt_ctx* c, hipStream_t st, const DevParams& P, const DevScene& S, const Images& img, DevCounters* ctr, dim3 grid,
+                 bool counted, bool pull)
 {
     const dim3 block(kMegaThreads);
     // Trees up to 32 levels deep keep the whole traversal stack in LDS (8 KB per wave).  Deeper
@@ -447,7 +477,7 @@ void launchTrace(const pt_ctx* c, const DevParams& P, const DevScene& S, const I
     // and 10 % faster on the trees of this library's own builders, where shading weighs more.
     const bool three = c->wavesPerSimd != 4;
 #define PT_LAUNCH_TRACE(STACK_DEEP, COUNTED, WAVES, PULL) \
-    hipLaunchKernelGGL((renderKernel<32, STACK_DEEP, COUNTED, WAVES, PULL>), grid, block, 0, c->stream, P, S, img, ctr)
+    hipLaunchKernelGGL((renderKernel<32, STACK_DEEP, COUNTED, WAVES, PULL>), grid, block, 0, st, P, S, img, ctr)
 #define PT_LAUNCH_TRACE_4(STACK_DEEP, COUNTED)                            \
     do {                                                                  \
         if (three && pull) PT_LAUNCH_TRACE(STACK_DEEP, COUNTED, 3, true); \
@@ -463,29 +493,38 @@ void launchTrace(const pt_ctx* c, const DevParams& P, const DevScene& S, const I
 #undef PT_LAUNCH_TRACE
 }
 
-int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t frameStride, bool counted, bool firstPart = true,
-                 bool lastPart = true)
+// One launch (of a dispatch call's one or more) on launch lane `k`; with `overlap` its trace side goes to the
+// lane's stream.
+int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t frameStride, bool counted, int k, bool overlap,
+                 bool firstPart = true, bool lastPart = true)
 {
-    if (!c) return fail(PT_ERR_INVALID, "null context");
-    if (frameCount == 0) return PT_OK;
-    if (frameFirst == 0) return fail(PT_ERR_INVALID, "FrameCount starts at 1 (weight 1/FrameCount)");
-    if (frameStride == 0) return fail(PT_ERR_INVALID, "frame_stride must be >= 1");
-    DeviceGuard guard(c->device);
-    int rc = syncScene(c);
-    if (rc != PT_OK) return rc;
-
     DevParams P;
     DevScene S;
     fillLaunchBlocks(c, frameFirst, frameCount, frameStride, P, S);
-    if (firstPart) HIP_TRY(hipMemsetAsync(c->dCounters.ptr, 0, sizeof(DevCounters), c->stream));
-    DevCounters* ctr = (DevCounters*)c->dCounters.ptr;
+    pt_ctx::LaunchLane& L = c->lane[k];
+    const hipStream_t st = overlap ? L.stream : c->stream;  // the trace side's stream
+    if (overlap) {
+        // the lane's stream sees what the context's stream did for the scene, and the lane's buffers are free again
+        if (c->forkDirty) {
+            HIP_TRY(hipEventRecord(c->evFork, c->stream));
+            c->forkCount++;
+            c->forkDirty = false;
+        }
+        if (L.forkSeen != c->forkCount) {
+            HIP_TRY(hipStreamWaitEvent(st, c->evFork, 0));
+            L.forkSeen = c->forkCount;
+        }
+        if (L.used) HIP_TRY(hipStreamWaitEvent(st, L.evFree, 0));
+    }
+    DevCounters* ctr = (DevCounters*)c->dCounters[c->counterSet].ptr;
+    if (firstPart) HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(DevCounters), st));
     Images img{imagePtr(c, 0), imagePtr(c, 1), imagePtr(c, 2)};
-    if (firstPart) HIP_TRY(hipEventRecord(c->evStart, c->stream));
+    if (firstPart) HIP_TRY(hipEventRecord(c->evStart, st));
     if (c->pipeline == 0) {
-        // Blocks are launched costliest first: the cost of a tile (ticks its waves lived in the previous
+        // Items are taken costliest first: the cost of a tile (ticks its waves lived in the lane's previous
         // launch) varies by an order of magnitude, and a launch that reaches its expensive tiles last
         // ends in a long, nearly empty tail.  A tile whose cost exceeds a fraction of the launch's
-        // lower bound has its samples spread over several blocks, so that one wave is never the
+        // lower bound has its samples spread over several items, so that one wave is never the
         // critical path (small images, a few expensive tiles in a cheap frame).
         const size_t tiles = (size_t)P.tilesX * P.tilesY;
         if (frameCount > 65535u) return fail(PT_ERR_INVALID, "a megakernel launch takes at most 65535 frames");
@@ -497,79 +536,86 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
         // eighth at 256 x 256, where there are fewer tiles than waves.  Unless set by hand.
         const unsigned split = c->tileSplit >= 0 ? (unsigned)c->tileSplit : (tiles < slots ? 8u : 32u);
         const size_t capacity = tiles + (size_t)split * c->waveSlots;
-        if (c->tileCostTiles != tiles || c->blockCapacity != capacity) {
-            for (DeviceBuffer* b : {&c->dTileCost, &c->dTileParts, &c->dTileKey, &c->dTileKeySorted, &c->dTileIds, &c->dTileOrder,
-                                    &c->dPartsInOrder, &c->dBlockStart})
+        if (L.tileCostTiles != tiles || L.blockCapacity != capacity) {
+            for (DeviceBuffer* b : {&L.dTileCost, &L.dTileParts, &L.dTileKey, &L.dTileKeySorted, &L.dTileIds, &L.dTileOrder,
+                                    &L.dPartsInOrder, &L.dBlockStart})
                 HIP_TRY(b->ensure((tiles + 1) * 4));  // (the cost words are followed by the launch's work counter)
-            HIP_TRY(c->dBlockList.ensure(capacity * 8));
-            HIP_TRY(c->dBlockCount.ensure(4));
+            HIP_TRY(L.dBlockList.ensure(capacity * 8));
+            HIP_TRY(L.dBlockCount.ensure(4));
             std::vector<uint32_t> ids(tiles);
             for (size_t i = 0; i < tiles; i++) ids[i] = (uint32_t)i;
-            HIP_TRY(hipMemcpyAsync(c->dTileIds.ptr, ids.data(), tiles * 4, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));  // `ids` dies with this scope
-            c->tileSortBytes = 0;
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, c->tileSortBytes, (const uint32_t*)c->dTileKey.ptr,
-                                                                 (uint32_t*)c->dTileKeySorted.ptr, (const uint32_t*)c->dTileIds.ptr,
-                                                                 (uint32_t*)c->dTileOrder.ptr, (int)tiles, 0, 32, c->stream));
-            HIP_TRY(c->dTileSortTemp.ensure(c->tileSortBytes));
-            c->scanBytes = 0;
-            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, c->scanBytes, (const uint32_t*)c->dPartsInOrder.ptr,
-                                                     (uint32_t*)c->dBlockStart.ptr, (int)tiles, c->stream));
-            HIP_TRY(c->dScanTemp.ensure(c->scanBytes));
-            if (c->tileCostTiles != tiles) c->tileCostValid = false;
-            c->tileCostTiles = tiles;
-            c->blockCapacity = capacity;
+            HIP_TRY(hipMemcpyAsync(L.dTileIds.ptr, ids.data(), tiles * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));  // `ids` dies with this scope
+            L.tileSortBytes = 0;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, L.tileSortBytes, (const uint32_t*)L.dTileKey.ptr,
+                                                                 (uint32_t*)L.dTileKeySorted.ptr, (const uint32_t*)L.dTileIds.ptr,
+                                                                 (uint32_t*)L.dTileOrder.ptr, (int)tiles, 0, 32, st));
+            HIP_TRY(L.dTileSortTemp.ensure(L.tileSortBytes));
+            L.scanBytes = 0;
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, L.scanBytes, (const uint32_t*)L.dPartsInOrder.ptr,
+                                                     (uint32_t*)L.dBlockStart.ptr, (int)tiles, st));
+            HIP_TRY(L.dScanTemp.ensure(L.scanBytes));
+            if (L.tileCostTiles != tiles) L.tileCostValid = false;
+            L.tileCostTiles = tiles;
+            L.blockCapacity = capacity;
         }
-        HIP_TRY(c->dSamples.ensure((size_t)frameCount * (size_t)c->width * c->height * 48u));
-        P.samples = (float*)c->dSamples.ptr;
+        HIP_TRY(L.dSamples.ensure((size_t)frameCount * (size_t)c->width * c->height * 48u));
+        P.samples = (float*)L.dSamples.ptr;
         P.pixels = (unsigned long long)c->width * c->height;
-        P.tileCost = (unsigned int*)c->dTileCost.ptr;
+        P.tileCost = (unsigned int*)L.dTileCost.ptr;
         P.workNext = P.tileCost + tiles;
         P.blockList = nullptr;
         P.blockCount = nullptr;
         size_t gridBlocks = tiles;
-        if (c->tileCostValid && c->tileOrdering) {
-            // at least four samples per block, at most 255 blocks per tile
+        if (L.tileCostValid && c->tileOrdering) {
+            // at least four samples per item, at most 255 items per tile
             const unsigned maxParts = split == 0 ? 1u : std::max(1u, std::min(255u, frameCount / 4u));
             const unsigned tb = 256, tg = (unsigned)((tiles + tb - 1) / tb);
-            hipLaunchKernelGGL(planPartsKernel, dim3(1), dim3(1024), 0, c->stream, (const unsigned*)c->dTileCost.ptr, (unsigned)tiles,
-                               slots, std::max(1u, split), maxParts, (unsigned*)c->dTileParts.ptr,
-                               (unsigned*)c->dTileKey.ptr);
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(c->dTileSortTemp.ptr, c->tileSortBytes, (const uint32_t*)c->dTileKey.ptr,
-                                                                 (uint32_t*)c->dTileKeySorted.ptr, (const uint32_t*)c->dTileIds.ptr,
-                                                                 (uint32_t*)c->dTileOrder.ptr, (int)tiles, 0, 32, c->stream));
-            hipLaunchKernelGGL(gatherPartsKernel, dim3(tg), dim3(tb), 0, c->stream, (const unsigned*)c->dTileOrder.ptr,
-                               (const unsigned*)c->dTileParts.ptr, (unsigned)tiles, (unsigned*)c->dPartsInOrder.ptr);
-            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->dScanTemp.ptr, c->scanBytes, (const uint32_t*)c->dPartsInOrder.ptr,
-                                                     (uint32_t*)c->dBlockStart.ptr, (int)tiles, c->stream));
-            hipLaunchKernelGGL(fillBlocksKernel, dim3(tg), dim3(tb), 0, c->stream, (const unsigned*)c->dTileOrder.ptr,
-                               (const unsigned*)c->dPartsInOrder.ptr, (const unsigned*)c->dBlockStart.ptr, (unsigned)tiles,
-                               (unsigned)capacity, frameCount, (unsigned*)c->dBlockList.ptr, (unsigned*)c->dBlockCount.ptr);
+            hipLaunchKernelGGL(planPartsKernel, dim3(1), dim3(1024), 0, st, (const unsigned*)L.dTileCost.ptr, (unsigned)tiles,
+                               slots, std::max(1u, split), maxParts, (unsigned*)L.dTileParts.ptr,
+                               (unsigned*)L.dTileKey.ptr);
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(L.dTileSortTemp.ptr, L.tileSortBytes, (const uint32_t*)L.dTileKey.ptr,
+                                                                 (uint32_t*)L.dTileKeySorted.ptr, (const uint32_t*)L.dTileIds.ptr,
+                                                                 (uint32_t*)L.dTileOrder.ptr, (int)tiles, 0, 32, st));
+            hipLaunchKernelGGL(gatherPartsKernel, dim3(tg), dim3(tb), 0, st, (const unsigned*)L.dTileOrder.ptr,
+                               (const unsigned*)L.dTileParts.ptr, (unsigned)tiles, (unsigned*)L.dPartsInOrder.ptr);
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(L.dScanTemp.ptr, L.scanBytes, (const uint32_t*)L.dPartsInOrder.ptr,
+                                                     (uint32_t*)L.dBlockStart.ptr, (int)tiles, st));
+            hipLaunchKernelGGL(fillBlocksKernel, dim3(tg), dim3(tb), 0, st, (const unsigned*)L.dTileOrder.ptr,
+                               (const unsigned*)L.dPartsInOrder.ptr, (const unsigned*)L.dBlockStart.ptr, (unsigned)tiles,
+                               (unsigned)capacity, frameCount, (unsigned*)L.dBlockList.ptr, (unsigned*)L.dBlockCount.ptr);
             HIP_TRY(hipGetLastError());
-            P.blockList = (const unsigned int*)c->dBlockList.ptr;
-            P.blockCount = (const unsigned int*)c->dBlockCount.ptr;
+            P.blockList = (const unsigned int*)L.dBlockList.ptr;
+            P.blockCount = (const unsigned int*)L.dBlockCount.ptr;
             gridBlocks = split == 0 ? tiles : capacity;  // the most items the list can hold (blocks past its end find none)
         }
         // The items are pulled by a grid of as many waves as the chip keeps resident (a block per item spends the end
         // of its life with idle lanes, and a launch of few samples per pixel is nothing but such ends: 1080p, benchmark
         // scene, one sample per pixel 2.5 -> 1.3 ms, 16 samples 12.1 -> 10.8 ms, 64 samples 43.7 -> 41.9 ms).
-        const bool pull = c->pullItems != 0;
+        const bool pull = c->pullItems;
         if (pull) gridBlocks = std::min<size_t>(gridBlocks, slots);
-        HIP_TRY(hipMemsetAsync(c->dTileCost.ptr, 0, (tiles + 1) * 4, c->stream));  // waves add the ticks they spend; work counter
-        c->tileCostValid = true;
+        HIP_TRY(hipMemsetAsync(L.dTileCost.ptr, 0, (tiles + 1) * 4, st));  // waves add the ticks they spend; work counter
+        L.tileCostValid = true;
         if (counted) {
             c->waveTimeCount = gridBlocks;
             HIP_TRY(c->dWaveTimes.ensure(c->waveTimeCount * 16));
-            HIP_TRY(hipMemsetAsync(c->dWaveTimes.ptr, 0, c->waveTimeCount * 16, c->stream));
+            HIP_TRY(hipMemsetAsync(c->dWaveTimes.ptr, 0, c->waveTimeCount * 16, st));
             P.waveTimes = (unsigned long long*)c->dWaveTimes.ptr;
         }
         const dim3 grid((unsigned)gridBlocks);
-        HIP_TRY(hipEventRecord(c->evTrace0, c->stream));
-        launchTrace(c, P, S, img, ctr, grid, counted, pull);
-        HIP_TRY(hipEventRecord(c->evTrace1, c->stream));
+        HIP_TRY(hipEventRecord(c->evTrace0, st));
+        launchTrace(c, st, P, S, img, ctr, grid, counted, pull);
+        HIP_TRY(hipEventRecord(c->evTrace1, st));
+        if (overlap) {
+            HIP_TRY(hipEventRecord(L.evTraced, st));
+            HIP_TRY(hipStreamWaitEvent(c->stream, L.evTraced, 0));
+        }
+        // samples are folded into the images in FrameCount order: all resolve passes on the one stream
         hipLaunchKernelGGL(resolveKernel, dim3((unsigned)((P.pixels + 255) / 256)), dim3(256), 0, c->stream, P, img);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->evResolve1, c->stream));
+        HIP_TRY(hipEventRecord(L.evFree, c->stream));
+        L.used = true;
         c->kernelTimed = true;
     } else {
         int rc2 = wavefrontDispatch(c, P, S, img, ctr, counted);
@@ -580,13 +626,29 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
     return PT_OK;
 }
 
-// A launch of many frames with no tile costs on record yet (first launch, new image size, new
+// A dispatch call.  One of many frames with no tile costs on record yet (first launch, new image size, new
 // geometry) is split: a short probe launch measures the costs, the rest runs from the plan made of them.
 // Frame order per pixel is unchanged, so are the results.
 int dispatchSplit(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t frameStride, bool counted)
 {
     if (!c) return fail(PT_ERR_INVALID, "null context");
-    if (c->pipeline != 0 || frameCount == 0) return dispatchImpl(c, frameFirst, frameCount, frameStride, counted);
+    if (frameCount == 0) return PT_OK;
+    if (frameFirst == 0) return fail(PT_ERR_INVALID, "FrameCount starts at 1 (weight 1/FrameCount)");
+    if (frameStride == 0) return fail(PT_ERR_INVALID, "frame_stride must be >= 1");
+    DeviceGuard guard(c->device);
+    int rc = syncScene(c);
+    if (rc != PT_OK) return rc;
+    // Calls may overlap on the library's own stream only (a caller's stream may be under graph capture, where work
+    // forked onto other streams has to be joined before the capture ends), with the megakernel, uncounted.  1080p,
+    // benchmark scene, ms per call without / with: one frame 1.39 / 1.02, two 2.03 / 1.69, four 3.27 / 2.99, eight
+    // 5.83 / 5.60, sixteen 11.08 / 10.87, sixty-four 42.2 / 41.9: long launches gain a per cent or two and would no
+    // longer be timed one by one, so it is calls of few frames that do.
+    const bool allowed = c->pipeline == 0 && !counted && c->stream == c->ownStream;
+    const bool overlap = allowed && (c->overlap < 0 ? frameCount <= 8u : c->overlap != 0);
+    // (three calls in flight are 7 % faster than two with one frame per call, 2 % with two, and slower from eight on)
+    const int k = overlap ? (c->lastLane = (c->lastLane + 1) % (frameCount <= 2u ? kLaunchLanes : 2)) : 0;
+    c->counterSet = k;
+    if (c->pipeline != 0) return dispatchImpl(c, frameFirst, frameCount, frameStride, counted, 0, false);
     // The megakernel writes one 48-byte record per (sample, pixel) and a resolve pass folds them into
     // the images; a launch takes as many frames as the sample buffer's budget holds.
     const uint64_t perFrame = (uint64_t)c->width * c->height * 48u;
@@ -594,8 +656,8 @@ int dispatchSplit(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t 
     uint32_t done = 0;
     while (done < frameCount) {
         uint32_t n = std::min(chunk, frameCount - done);
-        if (c->tileOrdering && !c->tileCostValid && n >= 8) n = n >= 64 ? 4u : 2u;  // probe: measure tile costs first
-        int rc = dispatchImpl(c, frameFirst + done * frameStride, n, frameStride, counted, done == 0, done + n == frameCount);
+        if (c->tileOrdering && !c->lane[k].tileCostValid && n >= 8) n = n >= 64 ? 4u : 2u;  // probe: measure tile costs first
+        rc = dispatchImpl(c, frameFirst + done * frameStride, n, frameStride, counted, k, overlap, done == 0, done + n == frameCount);
         if (rc != PT_OK) return rc;
         done += n;
     }
@@ -649,8 +711,16 @@ int pt_create(int device, int width, int height, pt_ctx** out)
         HIP_TRY(c->dImages[i].ensure(imageBytes));
         HIP_TRY(hipMemsetAsync(c->dImages[i].ptr, 0, imageBytes, c->stream));
     }
-    HIP_TRY(c->dCounters.ensure(sizeof(DevCounters)));
-    HIP_TRY(hipMemsetAsync(c->dCounters.ptr, 0, sizeof(DevCounters), c->stream));
+    for (DeviceBuffer& b : c->dCounters) {
+        HIP_TRY(b.ensure(sizeof(DevCounters)));
+        HIP_TRY(hipMemsetAsync(b.ptr, 0, sizeof(DevCounters), c->stream));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+    for (pt_ctx::LaunchLane& L : c->lane) {
+        HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&L.evTraced, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&L.evFree, hipEventDisableTiming));
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     *out = c.release();
     return PT_OK;
@@ -661,11 +731,21 @@ void pt_destroy(pt_ctx* c)
     if (!c) return;
     DeviceGuard guard(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DeviceBuffer* all[] = {&c->dSamples, &c->dTileCost, &c->dTileParts, &c->dTileKey, &c->dTileKeySorted, &c->dTileIds, &c->dTileOrder, &c->dTileSortTemp,
-                           &c->dPartsInOrder, &c->dBlockStart, &c->dBlockList, &c->dBlockCount, &c->dScanTemp, &c->dWaveTimes, &c->dRefNodes, &c->dRefPrims, &c->dRgbStaging, &c->dNodes, &c->dTriangles, &c->dShading, &c->dMaterials, &c->dTextures, &c->dTexels,
+    for (pt_ctx::LaunchLane& L : c->lane) {
+        if (L.stream) (void)hipStreamSynchronize(L.stream);
+        for (DeviceBuffer* b : {&L.dSamples, &L.dTileCost, &L.dTileParts, &L.dTileKey, &L.dTileKeySorted, &L.dTileIds, &L.dTileOrder, &L.dTileSortTemp,
+                                &L.dPartsInOrder, &L.dBlockStart, &L.dBlockList, &L.dBlockCount, &L.dScanTemp})
+            b->release();
+        if (L.evTraced) (void)hipEventDestroy(L.evTraced);
+        if (L.evFree) (void)hipEventDestroy(L.evFree);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+    }
+    if (c->evFork) (void)hipEventDestroy(c->evFork);
+    DeviceBuffer* all[] = {&c->dWaveTimes, &c->dRefNodes, &c->dRefPrims, &c->dRgbStaging, &c->dNodes, &c->dTriangles, &c->dShading, &c->dMaterials, &c->dTextures, &c->dTexels,
                            &c->dSrgbLut, &c->dEnvColorPdf, &c->dEnvSample, &c->dImages[0], &c->dImages[1],
-                           &c->dImages[2], &c->dCounters};
+                           &c->dImages[2]};
     for (DeviceBuffer* b : all) b->release();
+    for (DeviceBuffer& b : c->dCounters) b.release();
     for (DeviceBuffer& b : c->dWfState) b.release();
     c->dRayQ[0].release();
     c->dRayQ[1].release();
@@ -687,6 +767,7 @@ int pt_set_stream(pt_ctx* c, void* hipStream)
     DeviceGuard guard(c->device);
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->stream = hipStream ? (hipStream_t)hipStream : c->ownStream;
+    c->forkDirty = true;
     return PT_OK;
 }
 
@@ -719,7 +800,7 @@ int pt_upload_nodes(pt_ctx* c, const void* nodes48, size_t count)
     c->nodes.assign(p, p + count);
     c->geometryDirty = true;
     c->deviceGeometry = false;
-    c->tileCostValid = false;
+    forgetTileCosts(c);
     return PT_OK;
 }
 
@@ -731,7 +812,7 @@ int pt_upload_primitives(pt_ctx* c, const void* prims112, size_t count)
     c->prims.assign(p, p + count);
     c->geometryDirty = true;
     c->deviceGeometry = false;
-    c->tileCostValid = false;
+    forgetTileCosts(c);
     return PT_OK;
 }
 
@@ -1137,12 +1218,13 @@ int pt_dispatch_static(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint
     P.pixels = pixels;
     P.blockList = nullptr;
     P.blockCount = nullptr;
-    DevCounters* ctr = (DevCounters*)c->dCounters.ptr;  // allocated by pt_create
+    c->counterSet = 0;
+    DevCounters* ctr = (DevCounters*)c->dCounters[c->counterSet].ptr;  // allocated by pt_create
     Images img{imagePtr(c, 0), imagePtr(c, 1), imagePtr(c, 2)};
     HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(DevCounters), c->stream));
     HIP_TRY(hipMemsetAsync(base, 0, costBytes, c->stream));  // the array keeps the previous call's contents
     const uint32_t slots = c->wavesPerSimd != 4 ? c->waveSlots / 4u * 3u : c->waveSlots;
-    launchTrace(c, P, S, img, ctr, dim3((unsigned)std::min<size_t>(tiles, slots)), false, true);
+    launchTrace(c, c->stream, P, S, img, ctr, dim3((unsigned)std::min<size_t>(tiles, slots)), false, true);
     hipLaunchKernelGGL(resolveKernel, dim3((unsigned)((P.pixels + 255) / 256)), dim3(256), 0, c->stream, P, img);
     HIP_TRY(hipGetLastError());
     c->timed = false;  // no events around this launch
@@ -1227,7 +1309,7 @@ int pt_get_stats(pt_ctx* c, pt_stats* out)
     if (!c || !out) return fail(PT_ERR_INVALID, "null argument");
     DeviceGuard guard(c->device);
     DevCounters h{};
-    HIP_TRY(hipMemcpyAsync(&h, c->dCounters.ptr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&h, c->dCounters[c->counterSet].ptr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     out->samples = h.samples;
     out->rays_closest = h.raysClosest;
@@ -1279,7 +1361,8 @@ int pt_scene_bytes(pt_ctx* c, uint64_t* nodeBytes, uint64_t* triangleBytes, uint
 // cut into launches whose sample records fit); 9: megakernel run by resident waves that pull the
 // work items off a counter (1, the default) or by one block per item (0); 10: device BVH
 // builder: clustering search radius (0 = Morton radix tree); 11: megakernel compiled for 3 or 4 waves per SIMD
-// (0 = the default, 3).
+// (0 = the default, 3); 12: the trace launches of consecutive dispatch calls may overlap (1), never do (0), or do for
+// calls of at most 8 frames (-1, the default).
 int pt_debug_set_tuning(pt_ctx* c, int key, int value)
 {
     if (!c) return fail(PT_ERR_INVALID, "null context");
@@ -1319,6 +1402,10 @@ int pt_debug_set_tuning(pt_ctx* c, int key, int value)
     case 9:
         if (value != 0 && value != 1) return fail(PT_ERR_INVALID, "pull_items must be 0 or 1");
         c->pullItems = value != 0;
+        return PT_OK;
+    case 12:
+        if (value < -1 || value > 1) return fail(PT_ERR_INVALID, "overlap_calls must be -1 (calls of few frames), 0 or 1");
+        c->overlap = value;
         return PT_OK;
     case 11:
         if (value != 0 && value != 3 && value != 4) return fail(PT_ERR_INVALID, "waves per SIMD must be 0 (automatic), 3 or 4");
@@ -1360,7 +1447,7 @@ int pt_debug_get_profile(pt_ctx* c, uint64_t out16[16])
     if (!c || !out16) return fail(PT_ERR_INVALID, "null argument");
     DeviceGuard guard(c->device);
     DevCounters h{};
-    HIP_TRY(hipMemcpyAsync(&h, c->dCounters.ptr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&h, c->dCounters[c->counterSet].ptr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int i = 0; i < 16; i++) out16[i] = h.profile[i];
     return PT_OK;
@@ -1373,7 +1460,7 @@ int pt_debug_get_depth_histogram(pt_ctx* c, uint64_t out32[32])
     if (!c || !out32) return fail(PT_ERR_INVALID, "null argument");
     DeviceGuard guard(c->device);
     DevCounters h{};
-    HIP_TRY(hipMemcpyAsync(&h, c->dCounters.ptr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&h, c->dCounters[c->counterSet].ptr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int i = 0; i < 32; i++) out32[i] = h.depthRays[i];
     return PT_OK;
@@ -1520,7 +1607,7 @@ int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count)
     // triangles).
     c->deviceGeometry = false;
     c->geometryDirty = true;
-    c->tileCostValid = false;
+    forgetTileCosts(c);
     c->nodes.clear();
     c->prims.clear();
     const int n = (int)count;
@@ -1634,7 +1721,7 @@ int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count)
     }
     HIP_TRY(hipStreamSynchronize(st));  // the scratch buffers die with this scope
     c->maxDepth = height;
-    c->tileCostValid = false;
+    forgetTileCosts(c);
     c->deviceGeometry = true;
     c->geometryDirty = false;
     c->nodes.clear();

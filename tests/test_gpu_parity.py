@@ -560,6 +560,70 @@ def test_four_wave_kernel_and_scheduler_thresholds_give_the_same_image():
             assert images[name][k].tobytes() == images["default"][k].tobytes(), (name, k)
 
 
+def test_overlapping_calls_keep_frame_order_and_the_last_calls_counters():
+    """Dispatch calls of few frames trace on streams of their own, two or three calls in flight at a time,
+    and only their resolve passes are ordered.  A run of one-frame calls, interleaved with the calls that
+    have to wait for them (a read, a clear, a scale, new parameters, the static dispatch, a long call),
+    must leave the bits the oracle computes frame by frame; the counters are those of the last call alone;
+    on a caller's stream nothing overlaps and the bits are the same."""
+    import torch
+    w, h = 104, 72
+    o, g = _pair("TorusMixed", w, h)
+    p = R.default_params(w, h)
+    p.max_bounces = 5
+    g.set_params(p)
+    cpu = o.render(p, w, h, 1, 24, 1)
+    runs = {}
+    for name, tuning in {"never": dict(overlap_calls=0), "few-frames": dict(overlap_calls=-1), "always": dict(overlap_calls=1)}.items():
+        g.set_tuning(**tuning)
+        g.clear()
+        for f in range(1, 13):  # one frame per call: three calls in flight
+            g.dispatch(f, 1, 1)
+        assert g.stats().samples == w * h  # the last call's, not the sum of those still running
+        mid = g.read_image(0)  # waits for all twelve
+        g.dispatch(13, 3, 1)  # two calls in flight
+        g.dispatch(16, 2, 1)
+        g.dispatch_static(18, 1, 1)  # on the context's stream, behind every resolve pass
+        assert g.stats().samples == w * h
+        g.dispatch(19, 6, 1)
+        assert g.stats().samples == w * h * 6
+        runs[name] = [g.read_image(k) for k in range(3)] + [mid]
+    _assert_images_equal(runs["never"][:3], cpu[:3], cpu[3], "24 frames in calls of 1, 3, 2, 1 and 6")
+    for name in ("few-frames", "always"):
+        for k in range(4):
+            assert runs[name][k].tobytes() == runs["never"][k].tobytes(), (name, k)
+    # work between the calls that the next trace must see (parameters) or that must see the traces (clear, scale)
+    g.set_tuning(overlap_calls=1)
+    q = R.default_params(w, h)
+    q.max_bounces = 2
+    want = []
+    for setting in (0, 1):
+        g.set_tuning(overlap_calls=setting)
+        g.set_params(p)
+        g.clear()
+        g.dispatch(1, 1, 1)
+        g.dispatch(2, 1, 1)
+        g.clear()
+        g.set_params(q)
+        g.dispatch(1, 1, 1)
+        g.dispatch(2, 1, 1)
+        g.scale_images(0.5)
+        g.dispatch(3, 1, 1)
+        want.append([g.read_image(k) for k in range(3)])
+    for k in range(3):
+        assert want[0][k].tobytes() == want[1][k].tobytes(), k
+    # a caller's stream: everything on that one stream
+    stream = torch.cuda.Stream()
+    g.set_stream(stream.cuda_stream)
+    g.set_params(p)
+    g.clear()
+    for f in range(1, 13):
+        g.dispatch(f, 1, 1)
+    stream.synchronize()
+    assert g.read_image(0).tobytes() == runs["never"][3].tobytes()
+    g.set_stream(0)
+
+
 @PIPELINES
 def test_traversal_stack_beyond_32_entries(pipeline):
     """Trees deeper than 32 levels keep 32 stack entries in LDS and the rest in private memory.  A chain

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time of one dispatch of the benchmark workload at 1, 2, 4 ... 64 samples per pixel per dispatch
 (the viewer's call pattern is one sample per dispatch).
-    python tools/spp_scan.py [pull_items [spp,spp,...]]      # pull_items: 1 (default) or 0
+    python tools/spp_scan.py [spp,spp,... [key=value tuning settings ...]]
 """
 import os
 import sys
@@ -15,10 +15,10 @@ work = bench.build_workload(A)
 g = R.Renderer(1920, 1080)
 g.upload_nodes(work["nodes"]); g.upload_primitives(work["prims"]); g.upload_materials(work["mats"]); g.upload_environment(work["hdri"], work["cache"])
 p = R.default_params(1920, 1080); p.max_bounces = 8; g.set_params(p)
-if len(sys.argv) > 1:
-    g.set_tuning(pull_items=int(sys.argv[1]))
+if len(sys.argv) > 2:
+    g.set_tuning(**{k: int(v) for k, v in (item.split("=") for item in sys.argv[2:])})
 import time
-for spp in ([int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else (1, 2, 4, 8, 16, 64)):
+for spp in ([int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else (1, 2, 4, 8, 16, 64)):
     g.clear(); g.dispatch(1, spp, 1); g.synchronize()
     n = max(4, 64 // spp)
     t0 = time.perf_counter(); rays = 0; f = 1
