@@ -34,8 +34,8 @@ for cfg, shape in (("c2", "scene=dragonglass width=1920 height=1080 spp_per_step
     t = json.load(open(pmc))
     t["source"] = f"gpurun_out/prof_{tag}_{cfg} (tools/profile_gpu.sh: rocprofv3 --kernel-trace --stats, then one --pmc run per counter group)"
     json.dump(t, open(pmc, "w"), indent=1, sort_keys=True)
-    for f in glob.glob(os.path.join(prof, "kt", "**", "*kernel_stats.csv"), recursive=True):
-        shutil.copy(f, os.path.join(dst, f"{prefix}_{cfg}_kernel_stats.csv"))
+    stats = glob.glob(os.path.join(prof, "kt", "**", "*kernel_stats.csv"), recursive=True)
+    shutil.copy(max(stats, key=os.path.getmtime), os.path.join(dst, f"{prefix}_{cfg}_kernel_stats.csv"))  # (the newest run's)
     out = os.path.join(dst, "pmc_summary.json" if cfg == "c2" else f"{prefix}_{cfg}_pmc_summary.json")
     subprocess.run([py, os.path.join(ROOT, "tools", "make_pmc_summary.py"), os.path.relpath(pmc, ROOT), out] + shape.split(),
                    check=True, stdout=subprocess.DEVNULL, cwd=ROOT)

@@ -12,9 +12,20 @@ import sys
 from collections import defaultdict
 
 
+def newest_per_pass(paths):
+    """One file per pass directory, the newest: gpurun merges a run's output into what earlier runs with the
+    same tag left behind, under other process ids."""
+    best = {}
+    for path in paths:
+        d = os.path.dirname(path)
+        if d not in best or os.path.getmtime(path) > os.path.getmtime(best[d]):
+            best[d] = path
+    return sorted(best.values())
+
+
 def main(src, dst):
     out = {"source": src, "kernels": {}}
-    for path in glob.glob(os.path.join(src, "kt", "**", "*kernel_stats.csv"), recursive=True):
+    for path in newest_per_pass(glob.glob(os.path.join(src, "kt", "**", "*kernel_stats.csv"), recursive=True)):
         for row in csv.DictReader(open(path)):
             name = row["Name"].split("(")[0]
             out["kernels"][name] = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"]),
@@ -22,7 +33,7 @@ def main(src, dst):
                                     "percent": float(row["Percentage"])}
     counters = defaultdict(lambda: defaultdict(list))
     meta = {}
-    for path in glob.glob(os.path.join(src, "*", "**", "*counter_collection.csv"), recursive=True):
+    for path in newest_per_pass(glob.glob(os.path.join(src, "*", "**", "*counter_collection.csv"), recursive=True)):
         for row in csv.DictReader(open(path)):
             name = row["Kernel_Name"].split("(")[0]
             counters[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
