@@ -432,6 +432,26 @@ def main():
                                     "frac": resolve_bytes / avg_resolve_s / 1e9 / HBM_PEAK_GBS} if avg_resolve_s > 0 else None),
             },
         }
+        if world == 1 and not args.stub:
+            # Outside the timed region, for the record: the reference viewer's call pattern, one sample per
+            # pixel per dispatch call, on the library's own stream (where consecutive calls overlap).
+            try:
+                g.set_stream(0)
+                frames = 64
+                g.dispatch(1, 1, 1)
+                g.synchronize()
+                t1 = time.perf_counter()
+                for f in range(frames):
+                    g.dispatch(2 + f, 1, 1)
+                g.synchronize()
+                dt = (time.perf_counter() - t1) / frames
+                st1 = g.stats()
+                out["frame_by_frame"] = {"ms_per_frame": dt * 1e3, "value": (st1.rays_closest + st1.rays_any) / dt / 1e6,
+                                         "unit": "Mrays/s", "frames": frames, "spp_per_dispatch": 1}
+            except Exception as e:
+                out["frame_by_frame"] = {"error": str(e)}
+            finally:
+                g.set_stream(sr.stream.cuda_stream)
         if world == 1 and args.bvh == "host" and args.copies == 1 and not args.no_device_tree and not args.stub:
             # Outside the timed region, for the record: the same steps on the tree the GPU builder makes
             # of the same triangles (the reference's builder caps its split cost; see --bvh).
