@@ -312,6 +312,17 @@ int pt_read_image_rgb(pt_ctx* ctx, int which, float* rgb_out);
  * (the bottom row when displayed).  `exposure` is the Exposure uniform (PathTracingApplication.h
  * default 1.0).  Runs on the device; synchronises the stream. */
 int pt_read_display(pt_ctx* ctx, float exposure, unsigned char* rgb8_out);
+/* The two diagnostic views the reference's compute shader writes to the radiance image, in place of a
+ * frame, when it is compiled with DEBUG_ENABLED (Shaders/pathtracing.comp:216-223 calling
+ * Shaders/Library/debug.glsl:129-137): PT_DEBUG_VIEW_BVH is DebugBvh (:31-126), the number of leaves the
+ * pixel's pinhole ray reaches when every child box it enters is followed, as a heat map saturating at 100
+ * and purple where the shader's 16-entry stack overflows; PT_DEBUG_VIEW_HDRI_CACHE is DebugHdriCache
+ * (:7-28), the environment map with a red dot wherever one of 500 draws from the sampling cache lands.
+ * Needs pt_set_params (camera matrices), the uploaded tree and the environment; overwrites the radiance
+ * image (the bound one if images are bound), accumulates nothing; synchronises the stream. */
+#define PT_DEBUG_VIEW_BVH 1
+#define PT_DEBUG_VIEW_HDRI_CACHE 2
+int pt_debug_view(pt_ctx* ctx, int view);
 int pt_get_stats(pt_ctx* ctx, pt_stats* out);
 /* Milliseconds spent by the device in the most recent dispatch (HIP events on the context's
  * stream); synchronises. */

@@ -42,6 +42,8 @@ def oracle_lib():
         lib.oracle_render.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32,
                                       ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        lib.oracle_debug_view.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        lib.oracle_debug_view.restype = None
         lib.oracle_eval_math.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
         lib.oracle_display.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_float, ctypes.c_void_p]
         lib.oracle_display.restype = None
@@ -163,6 +165,13 @@ class Oracle:
         c = np.ascontiguousarray(cache_rgb, dtype=np.float32)
         h, w = a.shape[:2]
         self._lib.oracle_set_environment(self._h, _ptr(a), _ptr(c), w, h)
+
+    def debug_view(self, params, width, height, view, threads=0):
+        """The shader's DEBUG_ENABLED output (1 = DebugBvh heat map, 2 = DebugHdriCache): (h, w, 4) float32."""
+        out = np.zeros((height, width, 4), np.float32)
+        assert ctypes.sizeof(params) == self._lib.oracle_sizeof_params()
+        self._lib.oracle_debug_view(self._h, ctypes.byref(params), width, height, int(view), _ptr(out), threads)
+        return out
 
     def render(self, params, width, height, frame_first=1, frame_count=1, frame_stride=1, images=None, rows=None,
                threads=0):

@@ -33,6 +33,10 @@
 //     zero direction component yields 0 * inf = NaN for that slab, and this choice drops the slab from
 //     the test instead of turning the whole box into a miss or a hit by operand order;
 //   * the dead primary trace at pathtracing.comp:237 has no observable effect and is not run.
+// The two DEBUG_ENABLED views of Library/debug.glsl are restated as well (DebugBvh, DebugHdriCache); the
+// reference holds no image of either, so they are parity-unpinned like the shading: tests/test_host_misc.py
+// checks the values that follow from the shader text by hand.  DebugBvh's seventeenth push lands in spare
+// slots like the traversal's.
 #include <atomic>
 #include <cmath>
 #include <cstdint>
@@ -995,6 +999,78 @@ static HitInfo HitBvh(Ctx& c, Ray ray, bool any)
     return best;
 }
 
+// ------------------------------------------------------------------ Library/debug.glsl
+// The two views the shader writes instead of a frame when it is compiled with DEBUG_ENABLED
+// (pathtracing.comp:216-223): both are pure functions of the pixel.
+static vec4 DebugHdriCache(const Ctx& c, vec2 uv)  // :7-28
+{
+    vec3 hdriColor = envBilinear(c.s->hdri, c.s->envW, c.s->envH, vec2{uv.x, -uv.y});
+    for (uint32_t i = 0u; i < 500u; i++) {
+        uint32_t XiState = i;
+        vec2 Xi = RandomValueVec2(XiState);
+        vec3 t = envBilinear(c.s->cache, c.s->envW, c.s->envH, Xi);
+        vec2 texcoord{t.x, t.y};
+        texcoord.y = 1.0f - texcoord.y;
+        vec2 d = uv - texcoord;
+        if (gl_sqrt(d.x * d.x + d.y * d.y) < 0.005f) hdriColor = {1.0f, 0.0f, 0.0f};  // distance(uv, texcoord)
+    }
+    return {hdriColor.x, hdriColor.y, hdriColor.z, 1.0f};
+}
+static vec4 DebugBvh(const Ctx& c, Ray ray)  // :31-126
+{
+    uint32_t hitCounter = 0;
+    const std::vector<BvhNode>& bvhNodes = c.s->nodes;
+    int stack[BVH_STACKSIZE + STACK_SPARE];  // (the shader's seventeenth push lands in the spare part, as in HitBvh)
+    int stackPointer = 0;
+    stack[stackPointer++] = 1;
+    while (stackPointer > 0) {
+        int top = stack[--stackPointer];
+        const BvhNode& node = bvhNodes[top];
+        if (node.n > 0) {
+            hitCounter++;
+        } else {
+            if (stackPointer < BVH_STACKSIZE) {
+                float dstLeft = FLT_MAX_;
+                float dstRight = FLT_MAX_;
+                if (node.left > 0) {
+                    const BvhNode& leftNode = bvhNodes[node.left];
+                    dstLeft = HitAABB(ray, {leftNode.AA[0], leftNode.AA[1], leftNode.AA[2]}, {leftNode.BB[0], leftNode.BB[1], leftNode.BB[2]});
+                }
+                if (node.right > 0) {
+                    const BvhNode& rightNode = bvhNodes[node.right];
+                    dstRight = HitAABB(ray, {rightNode.AA[0], rightNode.AA[1], rightNode.AA[2]}, {rightNode.BB[0], rightNode.BB[1], rightNode.BB[2]});
+                }
+                if (dstLeft > 0.0f && dstRight > 0.0f) {
+                    if (dstLeft < dstRight) {
+                        stack[stackPointer++] = node.right;
+                        stack[stackPointer++] = node.left;
+                    } else {
+                        stack[stackPointer++] = node.left;
+                        stack[stackPointer++] = node.right;
+                    }
+                } else if (dstLeft > 0.0f) {
+                    stack[stackPointer++] = node.left;
+                } else if (dstRight > 0.0f) {
+                    stack[stackPointer++] = node.right;
+                }
+            } else {
+                hitCounter = 0xFFFFFFFFu;
+                break;
+            }
+        }
+    }
+    if (hitCounter == 0xFFFFFFFFu) return {1.0f, 0.0f, 1.0f, 1.0f};  // stack overflow (purple)
+    const vec3 mapTex[] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 1.0f}, {0.0f, 1.0f, 1.0f},
+                           {0.0f, 1.0f, 0.0f}, {1.0f, 1.0f, 0.0f}, {1.0f, 0.0f, 0.0f}};
+    const float mapTexLen = 5.0f;
+    const float maxHeat = 100.0f;
+    float l = gl_clamp((float)hitCounter / maxHeat, 0.0f, 1.0f) * mapTexLen;
+    vec3 a = mapTex[(uint32_t)std::floor(l)];
+    vec3 b = mapTex[(uint32_t)std::ceil(l)];
+    float t = l - std::floor(l);
+    return {gl_mix(a.x, b.x, t), gl_mix(a.y, b.y, t), gl_mix(a.z, b.z, t), 1.0f};
+}
+
 // ---------------------------------------------------------------- pathtracing.comp
 static void PathTrace(Ctx& c, Ray ray, vec3& radianceResult, vec3& primaryAlbedoResult, vec3& primaryNormalResult,
                       uint32_t& rngState)  // :16-143
@@ -1291,6 +1367,43 @@ void oracle_render(void* sp, const void* params, int width, int height, uint32_t
         if (c.maxStack > total.maxStack) total.maxStack = c.maxStack;
     }
     if (countersOut) std::memcpy(countersOut, &total, sizeof(Counters));
+}
+
+// The shader's DEBUG_ENABLED output (pathtracing.comp:216-223: debug value of the pixel's pinhole ray stored
+// to the radiance image, nothing accumulated).  view 1 = DEBUG_BVH, 2 = DEBUG_HDRI_CACHE.
+void oracle_debug_view(void* sp, const void* params, int width, int height, int view, float* radiance, int threads)
+{
+    const Scene& s = *(Scene*)sp;
+    Params u;
+    std::memcpy(&u, params, sizeof(Params));
+    u.FrameDimensions[0] = (float)width;
+    u.FrameDimensions[1] = (float)height;
+    mat4 viewM, invProj;
+    std::memcpy(viewM.m, u.ViewMatrix, 64);
+    std::memcpy(invProj.m, u.InvProjMatrix, 64);
+    const mat4 invView = inverse(viewM);
+    if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    if (threads < 1) threads = 1;
+    std::atomic<int> nextRow(0);
+    auto worker = [&]() {
+        Ctx c;
+        c.s = &s;
+        c.u = u;
+        for (;;) {
+            int y = nextRow.fetch_add(1);
+            if (y >= height) break;
+            for (int x = 0; x < width; x++) {
+                vec2 uv = vec2{(float)x + 0.5f, (float)y + 0.5f} / vec2{u.FrameDimensions[0], u.FrameDimensions[1]};
+                vec4 v = view == 2 ? DebugHdriCache(c, uv) : DebugBvh(c, GeneratePinholeCameraRay(c, invProj, invView, uv));
+                float* o = radiance + 4 * ((size_t)y * width + x);
+                o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; t++) pool.emplace_back(worker);
+    worker();
+    for (auto& th : pool) th.join();
 }
 
 // Element-wise evaluation of the built-ins defined in oracle_math.h, for checking the device

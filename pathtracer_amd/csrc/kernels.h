@@ -254,7 +254,7 @@ PT_DEV void mulMat4(const float* M, float x, float y, float z, float w, float ou
 {
     for (int i = 0; i < 4; i++) out[i] = ((M[0 + i] * x + M[4 + i] * y) + M[8 + i] * z) + M[12 + i] * w;
 }
-PT_DEV void primaryRay(const DevParams& P, float u, float v, unsigned& rng, v3& ro, v3& rd)
+PT_DEV void pinholeRay(const DevParams& P, float u, float v, v3& ro, v3& rd)
 {
     float vp[4];
     mulMat4(P.invProj, u * 2.0f - 1.0f, v * 2.0f - 1.0f, 0.0f, 1.0f, vp);
@@ -265,6 +265,10 @@ PT_DEV void primaryRay(const DevParams& P, float u, float v, unsigned& rng, v3& 
     mulMat4(P.invView, direction.x, direction.y, direction.z, 0.0f, d4);
     ro = mk3(o4[0], o4[1], o4[2]);
     rd = mk3(d4[0], d4[1], d4[2]);
+}
+PT_DEV void primaryRay(const DevParams& P, float u, float v, unsigned& rng, v3& ro, v3& rd)
+{
+    pinholeRay(P, u, v, ro, rd);
     if (P.apertureSize != 0.0f) {  // thin lens (:166-187)
         const float* VM = P.view;
         v3 cameraForward = -mk3(VM[8], VM[9], VM[10]);
@@ -1198,6 +1202,87 @@ __global__ void displayKernel(const float4* __restrict__ in, unsigned char* __re
             out[i * 3 + 2] = (unsigned char)(a >> 16);
         }
     }
+}
+
+// The two views the reference's shader writes to the radiance image instead of a frame when it is built
+// with DEBUG_ENABLED (pathtracing.comp:216-223, Library/debug.glsl): one thread per pixel, nothing
+// accumulated.  view 1 (debug.glsl:31-126): the leaves the pixel's pinhole ray reaches when every child
+// box it enters is followed (no triangle tests, no pruning), as a heat map over 0..100, purple where the
+// shader's 16-entry stack overflows; walked over the reference's own node records.  view 2 (:7-28): the
+// environment map with a red dot wherever one of 500 draws from the sampling cache lands.
+__global__ void debugViewKernel(DevParams P, DevScene S, int view, const RefNodeAlign* __restrict__ nodes, float4* __restrict__ radiance)
+{
+    const unsigned x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= P.width || y >= P.height) return;
+    const float u = ((float)x + 0.5f) / P.frameW, v = ((float)y + 0.5f) / P.frameH;
+    float4 out;
+    if (view == 2) {
+        Bilerp q = bilerpSetup(u, -v, P.envW, P.envH);
+        const float4 c00 = S.envColorPdf[(size_t)q.y0 * P.envW + q.x0], c10 = S.envColorPdf[(size_t)q.y0 * P.envW + q.x1];
+        const float4 c01 = S.envColorPdf[(size_t)q.y1 * P.envW + q.x0], c11 = S.envColorPdf[(size_t)q.y1 * P.envW + q.x1];
+        v3 color = mk3(bilerp(q, c00.x, c10.x, c01.x, c11.x), bilerp(q, c00.y, c10.y, c01.y, c11.y), bilerp(q, c00.z, c10.z, c01.z, c11.z));
+        for (unsigned i = 0u; i < 500u; i++) {
+            unsigned state = i;
+            const float xi1 = randomValue(state);
+            const float xi2 = randomValue(state);
+            q = bilerpSetup(xi1, xi2, P.envW, P.envH);
+            const float2 t00 = S.envSample[(size_t)q.y0 * P.envW + q.x0], t10 = S.envSample[(size_t)q.y0 * P.envW + q.x1];
+            const float2 t01 = S.envSample[(size_t)q.y1 * P.envW + q.x0], t11 = S.envSample[(size_t)q.y1 * P.envW + q.x1];
+            const float tx = bilerp(q, t00.x, t10.x, t01.x, t11.x);
+            const float ty = 1.0f - bilerp(q, t00.y, t10.y, t01.y, t11.y);
+            const float dx = u - tx, dy = v - ty;
+            if (sqrt_(dx * dx + dy * dy) < 0.005f) color = mk3(1.0f, 0.0f, 0.0f);
+        }
+        out = make_float4(color.x, color.y, color.z, 1.0f);
+    } else {
+        v3 ro, rd;
+        pinholeRay(P, u, v, ro, rd);
+        const v3 inv = reciprocal3(rd);
+        unsigned count = 0u;
+        int stack[18];  // the shader's 16, and the two entries its last pushes write past them
+        int sp = 0;
+        stack[sp++] = 1;
+        while (sp > 0) {
+            const RefNodeAlign node = nodes[stack[--sp]];
+            if (node.n > 0) {
+                count++;
+            } else if (sp < 16) {
+                float dl = kFltMax, dr = kFltMax, t0;
+                if (node.left > 0) {
+                    const RefNodeAlign c = nodes[node.left];
+                    if (!hitAabb(ro, inv, c.AA[0], c.AA[1], c.AA[2], c.BB[0], c.BB[1], c.BB[2], dl, t0)) dl = -1.0f;
+                }
+                if (node.right > 0) {
+                    const RefNodeAlign c = nodes[node.right];
+                    if (!hitAabb(ro, inv, c.AA[0], c.AA[1], c.AA[2], c.BB[0], c.BB[1], c.BB[2], dr, t0)) dr = -1.0f;
+                }
+                if (dl > 0.0f && dr > 0.0f) {
+                    const bool leftFirst = dl < dr;
+                    stack[sp++] = leftFirst ? node.right : node.left;
+                    stack[sp++] = leftFirst ? node.left : node.right;
+                } else if (dl > 0.0f) {
+                    stack[sp++] = node.left;
+                } else if (dr > 0.0f) {
+                    stack[sp++] = node.right;
+                }
+            } else {
+                count = 0xffffffffu;
+                break;
+            }
+        }
+        if (count == 0xffffffffu) {
+            out = make_float4(1.0f, 0.0f, 1.0f, 1.0f);
+        } else {
+            const float map[6][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 1.0f}, {0.0f, 1.0f, 1.0f},
+                                     {0.0f, 1.0f, 0.0f}, {1.0f, 1.0f, 0.0f}, {1.0f, 0.0f, 0.0f}};
+            const float l = clamp_((float)count / 100.0f, 0.0f, 1.0f) * 5.0f;
+            const float fl = floorf(l);
+            const unsigned ia = (unsigned)fl, ib = (unsigned)ceilf(l);
+            const float t = l - fl;
+            out = make_float4(mix_(map[ia][0], map[ib][0], t), mix_(map[ia][1], map[ib][1], t), mix_(map[ia][2], map[ib][2], t), 1.0f);
+        }
+    }
+    radiance[(size_t)y * P.width + x] = out;
 }
 
 // Element-wise evaluation of the float32 building blocks, so tests can compare them bit for bit

@@ -1304,6 +1304,33 @@ int pt_read_display(pt_ctx* c, float exposure, unsigned char* rgb8Out)
     return PT_OK;
 }
 
+int pt_debug_view(pt_ctx* c, int view)
+{
+    if (!c) return fail(PT_ERR_INVALID, "null context");
+    if (view != PT_DEBUG_VIEW_BVH && view != PT_DEBUG_VIEW_HDRI_CACHE) return fail(PT_ERR_INVALID, "unknown debug view");
+    DeviceGuard guard(c->device);
+    int rc = syncScene(c);
+    if (rc != PT_OK) return rc;
+    DevParams P;
+    DevScene S;
+    fillLaunchBlocks(c, 1, 1, 1, P, S);
+    // the heat map walks the tree as the shader does, over the reference's node records: those of a device-built
+    // tree are on the device already, uploaded ones are copied there for this call
+    DeviceBuffer uploaded;
+    const RefNodeAlign* nodes = (const RefNodeAlign*)c->dRefNodes.ptr;
+    if (view == PT_DEBUG_VIEW_BVH && !c->deviceGeometry) {
+        HIP_TRY(uploaded.ensure(c->nodes.size() * sizeof(RefNodeAlign)));
+        HIP_TRY(hipMemcpyAsync(uploaded.ptr, c->nodes.data(), c->nodes.size() * sizeof(RefNodeAlign), hipMemcpyHostToDevice, c->stream));
+        nodes = (const RefNodeAlign*)uploaded.ptr;
+    }
+    const dim3 block(16, 16), grid((unsigned)((c->width + 15) / 16), (unsigned)((c->height + 15) / 16));
+    hipLaunchKernelGGL(debugViewKernel, grid, block, 0, c->stream, P, S, view, nodes, imagePtr(c, PT_IMAGE_RADIANCE));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));  // `uploaded` is freed with this scope
+    uploaded.release();
+    return PT_OK;
+}
+
 int pt_get_stats(pt_ctx* c, pt_stats* out)
 {
     if (!c || !out) return fail(PT_ERR_INVALID, "null argument");

@@ -126,6 +126,7 @@ SYMBOLS = {
     "pt_write_image": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "pt_read_image_rgb": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "pt_read_display": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]),
+    "pt_debug_view": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pt_get_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Stats)]),
     "pt_last_dispatch_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
     "pt_last_kernel_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),

@@ -208,6 +208,12 @@ class Renderer:
         check(self._lib.pt_read_display(self._h, float(exposure), _ptr(out)))
         return out
 
+    def debug_view(self, view):
+        """The reference shader's DEBUG_ENABLED output into the radiance image: 1 = BVH heat map, 2 = HDRI
+        sampling cache.  Returns the (height, width, 4) float32 image."""
+        check(self._lib.pt_debug_view(self._h, int(view)))
+        return self.read_image(0)
+
     def stats(self):
         s = Stats()
         check(self._lib.pt_get_stats(self._h, ctypes.byref(s)))

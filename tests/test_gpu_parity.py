@@ -443,6 +443,44 @@ def test_read_display_is_the_display_pass_of_the_radiance_image():
     assert np.array_equal(g.read_display(1.0), ob.display(ramp, 1.0))
 
 
+def test_debug_views_are_the_shaders_debug_output():
+    """pt_debug_view against the oracle's restatement of Library/debug.glsl, bit for bit: the BVH heat map
+    (on an uploaded tree, on a device-built tree traced by the oracle from its download, and on a chain
+    tree deep enough to overflow the shader's 16-entry stack: purple) and the HDRI-cache view."""
+    w, h = 160, 96
+    o, g = _pair("BunnyClearcoat", w, h)
+    p = R.default_params(w, h)
+    g.set_params(p)
+    heat = g.debug_view(1)
+    assert heat.tobytes() == o.debug_view(p, w, h, 1).tobytes()
+    assert len(np.unique(heat.reshape(-1, 4), axis=0)) > 20  # a picture, not a constant
+    assert np.array_equal(heat[..., 3], np.ones((h, w), np.float32))
+    cache = g.debug_view(2)
+    assert cache.tobytes() == o.debug_view(p, w, h, 2).tobytes()
+    assert np.any(np.all(cache[..., :3] == np.array([1, 0, 0], np.float32), axis=-1))  # red dots
+    # a frame dispatched afterwards starts from the debug image only if the caller does not clear: clear works
+    g.clear()
+    g.dispatch(1, 1, 1)
+    cpu = o.render(p, w, h, 1, 1, 1)
+    _assert_images_equal([g.read_image(k) for k in range(3)], cpu[:3], cpu[3], "frame after a debug view")
+    # device-built tree: the oracle walks the downloaded reference-layout tree
+    nodes, prims, mats = built_scene("BunnyClearcoat")
+    g.build_bvh_device(prims)
+    dn, dp = g.download_bvh()
+    o.set_scene(dn, dp, mats)
+    assert g.debug_view(1).tobytes() == o.debug_view(p, w, h, 1).tobytes()
+    # chain tree, 40 levels: the far child of every level waits on the stack
+    nodes40, cprims = _chain_tree(40)
+    cmats = np.array([scenes.material(albedo=(0.7, 0.6, 0.5), roughness=0.6)], dtype=scenes.MATERIAL_DTYPE)
+    o.set_scene(R.align_nodes(nodes40), R.align_primitives(cprims), cmats)
+    g.upload_nodes(R.align_nodes(nodes40))
+    g.upload_primitives(R.align_primitives(cprims))
+    g.upload_materials(cmats)
+    deep = g.debug_view(1)
+    assert deep.tobytes() == o.debug_view(p, w, h, 1).tobytes()
+    assert np.any(np.all(deep == np.array([1, 0, 1, 1], np.float32), axis=-1))  # overflow: purple
+
+
 def test_error_behaviour():
     g = R.Renderer(32, 32)
     with pytest.raises(L.PtError) as e:

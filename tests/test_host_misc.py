@@ -185,6 +185,38 @@ def test_oracle_renders_plausible_image_and_is_thread_invariant():
     assert rad[-4:, :, :3].mean() > 0.1
 
 
+def test_oracle_debug_views_known_answers():
+    """Values that follow from Library/debug.glsl by hand (the reference holds no images of these views:
+    beyond these the views are parity-unpinned).  A tree whose root is a leaf: every ray counts exactly one
+    leaf (:46-49, no box test on the root), l = 1/100 * 5, mix(black, blue, 0.05).  A real tree: the count
+    over the heat map's ramp is monotone (black -> blue -> cyan -> green), never purple with 16 entries to
+    spare, and zero where the ray misses the root's children.  The HDRI view: every texel is the environment's
+    colour or pure red."""
+    o = _oracle_scene("TorusMixed")
+    p = R.default_params(40, 24)
+    # root leaf
+    nodes = np.zeros((2, 12), np.float32)
+    ni = nodes.view(np.int32)
+    ni[1, 2], ni[1, 3] = 1, 0
+    _, prims, mats = built_scene("TorusMixed")
+    leaf = ob.Oracle()
+    leaf.set_scene(nodes, prims[:1], mats)
+    img = leaf.debug_view(p, 40, 24, 1)
+    want = np.float32(0.0) * (np.float32(1.0) - np.float32(0.05)) + np.float32(1.0) * np.float32(np.float32(np.float32(1.0) / np.float32(100.0)) * np.float32(5.0))
+    assert np.all(img[..., 2] == want) and np.all(img[..., :2] == 0) and np.all(img[..., 3] == 1)
+    # a real tree
+    heat = o.debug_view(p, 40, 24, 1, threads=1)
+    assert heat.tobytes() == o.debug_view(p, 40, 24, 1, threads=4).tobytes()
+    rgb = heat[..., :3].reshape(-1, 3)
+    assert not np.any(np.all(rgb == np.array([1, 0, 1], np.float32), axis=1))
+    assert np.any(np.all(rgb == 0, axis=1)) and np.any(rgb[:, 2] > 0)
+    assert np.all((rgb[:, 0] == 0) | (rgb[:, 2] == 0))  # red only past green: the ramp never mixes red with blue
+    view = o.debug_view(p, 40, 24, 2)
+    red = np.all(view[..., :3] == np.array([1, 0, 0], np.float32), axis=-1)
+    assert 0 < red.sum() < red.size
+    assert np.isfinite(view).all() and np.all(view[..., 3] == 1)
+
+
 def test_oracle_frame_sequence_equals_single_call():
     o = _oracle_scene("TorusMixed")
     p = R.default_params(32, 32)
