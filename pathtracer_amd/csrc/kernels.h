@@ -161,11 +161,125 @@ PT_DEV void stackPop(Query& q, const int* stack, const int* deep)
     q.top = stackGet<STRIDE, LDS_DEPTH>(stack, deep, q.sp);
 }
 
+#ifndef PT_WIDE_NODES
+#define PT_WIDE_NODES 0
+#endif
+// One level of collapseKernel's sweep: every node of the frontier becomes a four-wide node that holds, for each
+// of its two children, the child itself if that is a leaf and the child's two children otherwise.
+__global__ void collapseKernel(const DevNode* __restrict__ in, DevNode4* __restrict__ out, const int2* __restrict__ frontier,
+                               unsigned count, int2* __restrict__ next, unsigned* __restrict__ counters)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int2 item = frontier[i];
+    const DevNode n = in[item.x];
+    DevNode4 w;
+    for (int k = 0; k < 4; k++) {
+        w.child[k] = 0;
+        w.pad[k] = 0;
+        for (int a = 0; a < 3; a++) w.lo[a][k] = w.hi[a][k] = 0.0f;
+    }
+    // Start from the two children; while a slot is free, the interior entry with the largest surface area is
+    // replaced by its own two children.
+    float mn[4][3], mx[4][3];
+    int ref[4];
+    int used = 2;
+    for (int a = 0; a < 3; a++) {
+        mn[0][a] = n.lmin[a], mx[0][a] = n.lmax[a];
+        mn[1][a] = n.rmin[a], mx[1][a] = n.rmax[a];
+    }
+    ref[0] = n.left, ref[1] = n.right;
+    while (used < 4) {
+        int pick = -1;
+        float bestArea = -1.0f;
+        for (int k = 0; k < used; k++) {
+            if (ref[k] <= 0) continue;
+            const float dx = mx[k][0] - mn[k][0], dy = mx[k][1] - mn[k][1], dz = mx[k][2] - mn[k][2];
+            const float area = dx * dy + dy * dz + dz * dx;
+            if (area > bestArea) bestArea = area, pick = k;
+        }
+        if (pick < 0) break;
+        const DevNode m = in[ref[pick]];
+        for (int a = 0; a < 3; a++) {
+            mn[pick][a] = m.lmin[a], mx[pick][a] = m.lmax[a];
+            mn[used][a] = m.rmin[a], mx[used][a] = m.rmax[a];
+        }
+        ref[pick] = m.left;
+        ref[used++] = m.right;
+    }
+    for (int k = 0; k < used; k++) {
+        int r = ref[k];
+        if (r > 0) {  // an interior node: it gets a wide node of its own in the next level
+            const int dst = (int)atomicAdd(&counters[0], 1u);
+            next[atomicAdd(&counters[1], 1u)] = make_int2(r, dst);
+            r = dst;
+        }
+        w.child[k] = r;
+        for (int a = 0; a < 3; a++) w.lo[a][k] = mn[k][a], w.hi[a][k] = mx[k][a];
+    }
+    out[item.y] = w;
+}
+
 template <bool COUNT, int STRIDE = kBlockThreads, int LDS_DEPTH = 0>
 PT_DEV int queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc, int* deep = nullptr)
 {
     const bool hasNode = q.cur > 0;
     const bool doTri = q.leafPos < q.leafEnd;
+#if PT_WIDE_NODES
+    const unsigned nodeOff = (hasNode ? (unsigned)q.cur : 0u) << 7;
+    const unsigned triIdx16 = (doTri ? q.leafPos : 0u) << 4;
+    unsigned triOff;
+    asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(triOff) : "v"(triIdx16));
+    const float4* nrec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.wide) + nodeOff);
+    const float4* trec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.triangles) + triOff);
+    const float4 lox = nrec[0], loy = nrec[1], loz = nrec[2], hix = nrec[3], hiy = nrec[4], hiz = nrec[5];
+    const int4 kids = *reinterpret_cast<const int4*>(nrec + 6);
+    const float4 t0 = trec[0], t1 = trec[1], t2 = trec[2];
+    bool finished = false;
+    bool pop = false;
+    if (hasNode) {
+        if (COUNT) sc.nodeVisits++;
+        const float limit = q.bestT * kPruneMargin;
+        float d0, d1, d2, d3, e0, e1, e2, e3;
+        const bool h0 = hitAabb(q.ro, q.inv, lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, d0, e0) & !(e0 > limit) & (kids.x != 0);
+        const bool h1 = hitAabb(q.ro, q.inv, lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, d1, e1) & !(e1 > limit) & (kids.y != 0);
+        const bool h2 = hitAabb(q.ro, q.inv, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, d2, e2) & !(e2 > limit) & (kids.z != 0);
+        const bool h3 = hitAabb(q.ro, q.inv, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, d3, e3) & !(e3 > limit) & (kids.w != 0);
+        // the children entered, nearest first (a sorting network over (distance, reference), empty = farthest):
+        // the nearest goes on at once, the others wait on the stack, the farthest lowest
+        float k0 = h0 ? d0 : kFltMax, k1 = h1 ? d1 : kFltMax, k2 = h2 ? d2 : kFltMax, k3 = h3 ? d3 : kFltMax;
+        int r0 = h0 ? kids.x : 0, r1 = h1 ? kids.y : 0, r2 = h2 ? kids.z : 0, r3 = h3 ? kids.w : 0;
+#define PT_CSWAP(ka, ra, kb, rb)              \
+    {                                         \
+        const bool sw = kb < ka;              \
+        const float kt = sw ? kb : ka;        \
+        const int rt = sw ? rb : ra;          \
+        kb = sw ? ka : kb;                    \
+        rb = sw ? ra : rb;                    \
+        ka = kt;                              \
+        ra = rt;                              \
+    }
+        PT_CSWAP(k0, r0, k1, r1)
+        PT_CSWAP(k2, r2, k3, r3)
+        PT_CSWAP(k0, r0, k2, r2)
+        PT_CSWAP(k1, r1, k3, r3)
+        PT_CSWAP(k1, r1, k2, r2)
+#undef PT_CSWAP
+        const bool p3 = r3 != 0, p2 = r2 != 0, p1 = r1 != 0;
+        stackPut<STRIDE, LDS_DEPTH>(stack, deep, q.sp, q.top);
+        q.top = p3 ? r3 : q.top;
+        q.sp += p3;
+        stackPut<STRIDE, LDS_DEPTH>(stack, deep, q.sp, q.top);
+        q.top = p2 ? r2 : q.top;
+        q.sp += p2;
+        stackPut<STRIDE, LDS_DEPTH>(stack, deep, q.sp, q.top);
+        q.top = p1 ? r1 : q.top;
+        q.sp += p1;
+        if (COUNT) sc.maxStack = (unsigned)q.sp > sc.maxStack ? (unsigned)q.sp : sc.maxStack;
+        q.cur = r0 != 0 ? r0 : q.cur;
+        pop = !(h0 | h1 | h2 | h3);
+    }
+#else
     // Both records are requested up front by every calling lane -- record 0 of either array (always
     // allocated) stands in when the lane has no node or no leaf -- so the loads sit in straight-line
     // code and are all in flight before the first use.
@@ -202,6 +316,7 @@ PT_DEV int queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc, 
         q.cur = both ? (leftFirst ? left : right) : (hl ? left : right);
         pop = !(hl | hr);
     }
+#endif
     if (doTri) {
         // Moller-Trumbore with the shader's expressions (intersection.glsl:26-40); the edges and
         // their cross product come precomputed from the host.
@@ -525,7 +640,7 @@ template <int STACK, int DEEP, bool COUNT, int WAVES = PT_WAVES_PER_SIMD, bool P
 __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P, DevScene S, Images img, DevCounters* counters)
 {
     static_assert(kMegaThreads == 64, "one wave per block: the sample pool below is wave-wide");
-    __shared__ int s_stack[STACK * kMegaThreads];
+    __shared__ int s_stack[(STACK + PT_WIDE_NODES) * kMegaThreads];  // (wide nodes: a spare row for the push that is not one)
     int deepStack[DEEP > 0 ? DEEP : 1];
     __shared__ unsigned s_pixel[64];  // the tile's pixels that lie inside the image, compacted
     __shared__ unsigned s_depth[COUNT ? 32 : 1];  // counting build: closest-hit queries by path depth

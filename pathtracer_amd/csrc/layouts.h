@@ -94,6 +94,15 @@ struct alignas(64) DevNode {
 };
 static_assert(sizeof(DevNode) == 64, "");
 
+// Four-wide node: the boxes of up to four children, bound by bound, and their references (0 = empty slot).
+struct alignas(128) DevNode4 {
+    float lo[3][4];
+    float hi[3][4];
+    int32_t child[4];
+    int32_t pad[4];
+};
+static_assert(sizeof(DevNode4) == 128, "");
+
 // Ray/triangle record: vertex A, the two edges and their cross product, all computed on the
 // host with the reference's float expressions (intersection.glsl:23-25).
 struct alignas(16) DevTriangle {

@@ -112,6 +112,8 @@ struct pt_ctx {
     std::vector<PendingModel> models;
 
     // device side
+    DeviceBuffer dNodes4;
+    int wideLevels = 0;
     DeviceBuffer dNodes, dTriangles, dShading, dMaterials, dTextures, dTexels, dSrgbLut, dEnvColorPdf, dEnvSample;
     DeviceBuffer dImages[3];
     DeviceBuffer dCounters[kLaunchLanes];  // one set per launch lane (a call's launches may still run when the next calls start)
@@ -199,6 +201,41 @@ float4* imagePtr(pt_ctx* c, int which) { return c->bound[which] ? c->bound[which
 
 int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count);
 
+// Folds every other level of the binary tree in dNodes away: dNodes4, level by level from the root.
+int collapseTree(pt_ctx* c, size_t nodeCount)
+{
+    c->wideLevels = 0;
+    HIP_TRY(c->dNodes4.ensure((nodeCount + 2) * sizeof(DevNode4)));
+    HIP_TRY(hipMemsetAsync(c->dNodes4.ptr, 0, 2 * sizeof(DevNode4), c->stream));
+    if (c->rootRef <= 0) return PT_OK;  // the root is a leaf
+    DeviceBuffer frontier[2], counters;
+    HIP_TRY(frontier[0].ensure(nodeCount * sizeof(int2)));
+    HIP_TRY(frontier[1].ensure(nodeCount * sizeof(int2)));
+    HIP_TRY(counters.ensure(8));
+    const int2 root = make_int2(c->rootRef, 1);
+    unsigned h[2] = {2u, 0u};  // next free wide node (0: the dummy, 1: the root); size of the next frontier
+    HIP_TRY(hipMemcpyAsync(frontier[0].ptr, &root, sizeof(root), hipMemcpyHostToDevice, c->stream));
+    unsigned count = 1;
+    int cur = 0;
+    while (count > 0) {
+        HIP_TRY(hipMemcpyAsync(counters.ptr, h, 8, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(collapseKernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, (const DevNode*)c->dNodes.ptr,
+                           (DevNode4*)c->dNodes4.ptr, (const int2*)frontier[cur].ptr, count, (int2*)frontier[cur ^ 1].ptr,
+                           (unsigned*)counters.ptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h, counters.ptr, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        count = h[1];
+        h[1] = 0;
+        cur ^= 1;
+        c->wideLevels++;
+    }
+    frontier[0].release();
+    frontier[1].release();
+    counters.release();
+    return PT_OK;
+}
+
 int syncScene(pt_ctx* c)
 {
     if (!c->deviceGeometry && (c->nodes.empty() || c->prims.empty()))
@@ -244,11 +281,14 @@ int syncScene(pt_ctx* c)
         HIP_TRY(hipStreamSynchronize(c->stream));  // `packed` dies at the end of this scope
         c->rootRef = packed.rootRef;
         c->maxDepth = packed.maxDepth;
+        {
+            const int rcw = collapseTree(c, packed.nodes.size());
+            if (rcw != PT_OK) return rcw;
+        }
         c->nodeBytes = nb;
         c->triangleBytes = tb;
         c->shadingBytes = sb;
         c->geometryDirty = false;
-    c->forkDirty = true;  // (the builder's kernels ran on the context's stream)
         c->forkDirty = true;
     }
     if (c->texturesDirty) {
@@ -446,6 +486,7 @@ void fillLaunchBlocks(const pt_ctx* c, uint32_t frameFirst, uint32_t frameCount,
 
     S = DevScene{};
     S.nodes = (const DevNode*)c->dNodes.ptr;
+    S.wide = (const DevNode4*)c->dNodes4.ptr;
     S.triangles = (const DevTriangle*)c->dTriangles.ptr;
     S.shading = (const DevShading*)c->dShading.ptr;
     S.materials = (const DevMaterial*)c->dMaterials.ptr;
@@ -471,13 +512,13 @@ void launchTrace(const pt_ctx* c, hipStream_t st, const DevParams& P, const DevS
     // Trees up to 32 levels deep keep the whole traversal stack in LDS (8 KB per wave).  Deeper
     // ones keep 32 entries there and the rest in private memory (3 % slower than an all-LDS kernel
     // on a 5 M-triangle scene whose tree is 34 deep; a 40-entry LDS stack costs 6 %, a 48-entry one 13 %).
-    const bool deep = c->maxDepth > 32;
+    const bool deep = PT_WIDE_NODES ? 3 * c->wideLevels > 48 : c->maxDepth > 32;
     // Three waves per SIMD (168 VGPRs, next to nothing spilled) unless four are asked for (128 VGPRs, some 70
     // values spilled in the shading blocks): three are 2 % faster on the reference's tree of the benchmark scene
     // and 10 % faster on the trees of this library's own builders, where shading weighs more.
     const bool three = c->wavesPerSimd != 4;
 #define PT_LAUNCH_TRACE(STACK_DEEP, COUNTED, WAVES, PULL) \
-    hipLaunchKernelGGL((renderKernel<32, STACK_DEEP, COUNTED, WAVES, PULL>), grid, block, 0, st, P, S, img, ctr)
+    hipLaunchKernelGGL((renderKernel<(PT_WIDE_NODES ? 48 : 32), STACK_DEEP, COUNTED, WAVES, PULL>), grid, block, 0, st, P, S, img, ctr)
 #define PT_LAUNCH_TRACE_4(STACK_DEEP, COUNTED)                            \
     do {                                                                  \
         if (three && pull) PT_LAUNCH_TRACE(STACK_DEEP, COUNTED, 3, true); \
@@ -1748,9 +1789,15 @@ int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count)
     }
     HIP_TRY(hipStreamSynchronize(st));  // the scratch buffers die with this scope
     c->maxDepth = height;
+    c->rootRef = n > 1 ? 1 : c->rootRef;
+    {
+        const int rcw = collapseTree(c, devNodeCount);
+        if (rcw != PT_OK) return rcw;
+    }
     forgetTileCosts(c);
     c->deviceGeometry = true;
     c->geometryDirty = false;
+    c->forkDirty = true;  // (the builder's kernels ran on the context's stream)
     c->nodes.clear();
     c->prims.clear();
     c->deviceNodeCount = refNodeCount;

@@ -25,6 +25,7 @@ constexpr float kMinDielectricsF0 = 0.04f;
 
 struct DevScene {
     const DevNode* nodes;
+    const DevNode4* wide;  // the same tree with every other level folded away
     const DevTriangle* triangles;
     const DevShading* shading;
     const DevMaterial* materials;
