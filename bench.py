@@ -41,11 +41,11 @@ MALL_GATHER_GBS = 8600.0  # measured ceiling for random rows served by the Infin
 # The reference's Dragon.glb is missing; the Stanford dragon it is commonly built from has ~871 k
 # triangles.  The bunny (144 k) subdivided once (576 k) is the closest stand-in at hand.
 DEFAULT_SUBDIVIDE = 1
-# Canonical record sizes for algorithmic bytes per ray: one two-child node (2 AABBs + 2 refs),
+# Canonical record sizes for algorithmic bytes per ray: one four-wide node (4 AABBs + 4 refs),
 # one triangle (3 vertices padded), shading record, material record; one 48-byte record
 # (radiance, albedo, normal as three float4) per finished sample; 96 B of image traffic (three
 # RGBA32F texels read + written) per pixel and launch.
-S_NODE, S_TRI, S_SHADE, S_MAT, S_SAMPLE, S_ACC = 64, 48, 64, 80, 48, 96
+S_NODE, S_TRI, S_SHADE, S_MAT, S_SAMPLE, S_ACC = 128, 48, 64, 80, 48, 96
 
 SCENES = {  # name -> (metric label, default width, height, bounces)
     "dragonglass": ("1080p DragonGlass", 1920, 1080, 8),

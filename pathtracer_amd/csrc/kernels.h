@@ -119,7 +119,7 @@ PT_DEV void beginQuery(Query& q, int rootRef, v3 ro, v3 rd, bool isShadow) { beg
 enum QueryState : int { kQueryGoesOn = 0, kQueryDone = 1, kQueryOccluded = 2 };
 
 // Advances the query by one iteration and reports its state.  A lane can
-// hold an interior node to visit (`cur` > 0) and, next to it, a leaf whose triangles are still
+// hold a (four-wide) interior node to visit (`cur` > 0) and, next to it, a leaf whose triangles are still
 // being scanned (`leafPos` < `leafEnd`): reaching a leaf does not interrupt the walk, the leaf is
 // parked and its triangles are tested one per iteration while the lane goes on visiting nodes.  A
 // second leaf reference waits in `cur` (< 0) until the parked leaf is done, so leaves are scanned
@@ -161,13 +161,15 @@ PT_DEV void stackPop(Query& q, const int* stack, const int* deep)
     q.top = stackGet<STRIDE, LDS_DEPTH>(stack, deep, q.sp);
 }
 
-#ifndef PT_WIDE_NODES
-#define PT_WIDE_NODES 0
-#endif
-// One level of collapseKernel's sweep: every node of the frontier becomes a four-wide node that holds, for each
-// of its two children, the child itself if that is a leaf and the child's two children otherwise.
+// The traversal kernels walk a four-wide tree made of the binary one, level by level from the root (one launch
+// of collapseKernel per level: `frontier` holds (binary node, index of its wide node) pairs, `counters` the next
+// free wide node and the size of the next frontier).  A wide node starts from the binary node's two children;
+// while a slot is free, the interior entry with the largest surface area is replaced by its own two children
+// (`uniform`: both children are always opened instead, which at least halves the depth).  On the reference's
+// tree of the benchmark scene, whose builder caps its split cost, a ray then visits 6.0 nodes instead of 15.2.
+// Empty slots hold NaN boxes, which no ray enters.
 __global__ void collapseKernel(const DevNode* __restrict__ in, DevNode4* __restrict__ out, const int2* __restrict__ frontier,
-                               unsigned count, int2* __restrict__ next, unsigned* __restrict__ counters)
+                               unsigned count, int2* __restrict__ next, unsigned* __restrict__ counters, int uniform)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -177,10 +179,8 @@ __global__ void collapseKernel(const DevNode* __restrict__ in, DevNode4* __restr
     for (int k = 0; k < 4; k++) {
         w.child[k] = 0;
         w.pad[k] = 0;
-        for (int a = 0; a < 3; a++) w.lo[a][k] = w.hi[a][k] = 0.0f;
+        for (int a = 0; a < 3; a++) w.lo[a][k] = w.hi[a][k] = __builtin_nanf("");
     }
-    // Start from the two children; while a slot is free, the interior entry with the largest surface area is
-    // replaced by its own two children.
     float mn[4][3], mx[4][3];
     int ref[4];
     int used = 2;
@@ -189,7 +189,21 @@ __global__ void collapseKernel(const DevNode* __restrict__ in, DevNode4* __restr
         mn[1][a] = n.rmin[a], mx[1][a] = n.rmax[a];
     }
     ref[0] = n.left, ref[1] = n.right;
-    while (used < 4) {
+    auto open = [&](int k) {  // entry k gives way to its two children
+        const DevNode m = in[ref[k]];
+        for (int a = 0; a < 3; a++) {
+            mn[k][a] = m.lmin[a], mx[k][a] = m.lmax[a];
+            mn[used][a] = m.rmin[a], mx[used][a] = m.rmax[a];
+        }
+        ref[k] = m.left;
+        ref[used++] = m.right;
+    };
+    if (uniform) {
+        const bool second = ref[1] > 0;
+        if (ref[0] > 0) open(0);
+        if (second) open(1);
+    }
+    while (!uniform && used < 4) {
         int pick = -1;
         float bestArea = -1.0f;
         for (int k = 0; k < used; k++) {
@@ -199,13 +213,7 @@ __global__ void collapseKernel(const DevNode* __restrict__ in, DevNode4* __restr
             if (area > bestArea) bestArea = area, pick = k;
         }
         if (pick < 0) break;
-        const DevNode m = in[ref[pick]];
-        for (int a = 0; a < 3; a++) {
-            mn[pick][a] = m.lmin[a], mx[pick][a] = m.lmax[a];
-            mn[used][a] = m.rmin[a], mx[used][a] = m.rmax[a];
-        }
-        ref[pick] = m.left;
-        ref[used++] = m.right;
+        open(pick);
     }
     for (int k = 0; k < used; k++) {
         int r = ref[k];
@@ -225,39 +233,46 @@ PT_DEV int queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc, 
 {
     const bool hasNode = q.cur > 0;
     const bool doTri = q.leafPos < q.leafEnd;
-#if PT_WIDE_NODES
+    // Both records are requested up front by every calling lane -- record 0 of either array (always
+    // allocated) stands in when the lane has no node or no leaf -- so the loads sit in straight-line
+    // code and are all in flight before the first use.
+    // (32-bit byte offsets from the array bases: the loads then take a scalar base and a 32-bit lane
+    // offset, with no 64-bit address arithmetic in the loop; the host refuses arrays beyond 4 GB)
     const unsigned nodeOff = (hasNode ? (unsigned)q.cur : 0u) << 7;
     const unsigned triIdx16 = (doTri ? q.leafPos : 0u) << 4;
-    unsigned triOff;
+    unsigned triOff;  // x 48 as one full-rate shift-add (the compiler would fold it into a quarter-rate 32-bit multiply)
     asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(triOff) : "v"(triIdx16));
+    static_assert(sizeof(DevNode4) == 128 && sizeof(DevTriangle) == 48, "record sizes are wired into the offsets above");
     const float4* nrec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.wide) + nodeOff);
     const float4* trec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.triangles) + triOff);
     const float4 lox = nrec[0], loy = nrec[1], loz = nrec[2], hix = nrec[3], hiy = nrec[4], hiz = nrec[5];
     const int4 kids = *reinterpret_cast<const int4*>(nrec + 6);
     const float4 t0 = trec[0], t1 = trec[1], t2 = trec[2];
-    bool finished = false;
+    bool finished = false;  // query complete
     bool pop = false;
     if (hasNode) {
         if (COUNT) sc.nodeVisits++;
-        const float limit = q.bestT * kPruneMargin;
+        const float limit = q.bestT * kPruneMargin;  // bestT stays FLT_MAX for shadow rays
         float d0, d1, d2, d3, e0, e1, e2, e3;
-        const bool h0 = hitAabb(q.ro, q.inv, lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, d0, e0) & !(e0 > limit) & (kids.x != 0);
-        const bool h1 = hitAabb(q.ro, q.inv, lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, d1, e1) & !(e1 > limit) & (kids.y != 0);
-        const bool h2 = hitAabb(q.ro, q.inv, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, d2, e2) & !(e2 > limit) & (kids.z != 0);
-        const bool h3 = hitAabb(q.ro, q.inv, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, d3, e3) & !(e3 > limit) & (kids.w != 0);
-        // the children entered, nearest first (a sorting network over (distance, reference), empty = farthest):
-        // the nearest goes on at once, the others wait on the stack, the farthest lowest
+        const bool h0 = hitAabb(q.ro, q.inv, lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, d0, e0) & !(e0 > limit);
+        const bool h1 = hitAabb(q.ro, q.inv, lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, d1, e1) & !(e1 > limit);
+        const bool h2 = hitAabb(q.ro, q.inv, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, d2, e2) & !(e2 > limit);
+        const bool h3 = hitAabb(q.ro, q.inv, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, d3, e3) & !(e3 > limit);
+        // The children entered, nearest first by the shader's box distance (intersection.glsl:169-180 orders its
+        // two children by the same value), through a sorting network over (distance, reference) pairs in which a
+        // child not entered is the farthest: the nearest is visited next, the others wait on the stack, the
+        // farthest lowest.  A push that is not one writes the row above the stack's top, which nothing reads.
         float k0 = h0 ? d0 : kFltMax, k1 = h1 ? d1 : kFltMax, k2 = h2 ? d2 : kFltMax, k3 = h3 ? d3 : kFltMax;
         int r0 = h0 ? kids.x : 0, r1 = h1 ? kids.y : 0, r2 = h2 ? kids.z : 0, r3 = h3 ? kids.w : 0;
-#define PT_CSWAP(ka, ra, kb, rb)              \
-    {                                         \
-        const bool sw = kb < ka;              \
-        const float kt = sw ? kb : ka;        \
-        const int rt = sw ? rb : ra;          \
-        kb = sw ? ka : kb;                    \
-        rb = sw ? ra : rb;                    \
-        ka = kt;                              \
-        ra = rt;                              \
+#define PT_CSWAP(ka, ra, kb, rb)       \
+    {                                  \
+        const bool sw = kb < ka;       \
+        const float kt = sw ? kb : ka; \
+        const int rt = sw ? rb : ra;   \
+        kb = sw ? ka : kb;             \
+        rb = sw ? ra : rb;             \
+        ka = kt;                       \
+        ra = rt;                       \
     }
         PT_CSWAP(k0, r0, k1, r1)
         PT_CSWAP(k2, r2, k3, r3)
@@ -277,46 +292,8 @@ PT_DEV int queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc, 
         q.sp += p1;
         if (COUNT) sc.maxStack = (unsigned)q.sp > sc.maxStack ? (unsigned)q.sp : sc.maxStack;
         q.cur = r0 != 0 ? r0 : q.cur;
-        pop = !(h0 | h1 | h2 | h3);
+        pop = r0 == 0;
     }
-#else
-    // Both records are requested up front by every calling lane -- record 0 of either array (always
-    // allocated) stands in when the lane has no node or no leaf -- so the loads sit in straight-line
-    // code and are all in flight before the first use.
-    // (32-bit byte offsets from the array bases: the loads then take a scalar base and a 32-bit lane
-    // offset, with no 64-bit address arithmetic in the loop; the host refuses arrays beyond 4 GB)
-    const unsigned nodeOff = (hasNode ? (unsigned)q.cur : 0u) << 6;
-    const unsigned triIdx16 = (doTri ? q.leafPos : 0u) << 4;
-    unsigned triOff;  // x 48 as one full-rate shift-add (the compiler would fold it into a quarter-rate 32-bit multiply)
-    asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(triOff) : "v"(triIdx16));
-    static_assert(sizeof(DevNode) == 64 && sizeof(DevTriangle) == 48, "record sizes are wired into the offsets above");
-    const float4* nrec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + nodeOff);
-    const float4* trec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.triangles) + triOff);
-    const float4 n0 = nrec[0], n1 = nrec[1], n2 = nrec[2], n3 = nrec[3];
-    const float4 t0 = trec[0], t1 = trec[1], t2 = trec[2];
-    bool finished = false;  // query complete
-    bool pop = false;
-    if (hasNode) {
-        if (COUNT) sc.nodeVisits++;
-        float dl, dr, t0l, t0r;
-        const bool inl = hitAabb(q.ro, q.inv, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, dl, t0l);
-        const bool inr = hitAabb(q.ro, q.inv, n2.x, n2.y, n2.z, n3.x, n3.y, n3.z, dr, t0r);
-        const float limit = q.bestT * kPruneMargin;  // bestT stays FLT_MAX for shadow rays
-        const bool hl = inl & !(t0l > limit);
-        const bool hr = inr & !(t0r > limit);
-        const int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
-        const bool both = hl & hr;
-        const bool leftFirst = dl < dr;  // intersection.glsl:169-180 (both children hit: the shader's values)
-        if (both) {  // postpone the far child
-            stackPut<STRIDE, LDS_DEPTH>(stack, deep, q.sp, q.top);
-            q.top = leftFirst ? right : left;
-            q.sp++;
-            if (COUNT) sc.maxStack = (unsigned)q.sp > sc.maxStack ? (unsigned)q.sp : sc.maxStack;
-        }
-        q.cur = both ? (leftFirst ? left : right) : (hl ? left : right);
-        pop = !(hl | hr);
-    }
-#endif
     if (doTri) {
         // Moller-Trumbore with the shader's expressions (intersection.glsl:26-40); the edges and
         // their cross product come precomputed from the host.
@@ -341,7 +318,7 @@ PT_DEV int queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc, 
         q.leafPos++;
         finished = q.isShadow & ok;  // occluded
     }
-    if (pop) stackPop<STRIDE, LDS_DEPTH>(q, stack, deep);  // both children missed: next sub-tree off the stack
+    if (pop) stackPop<STRIDE, LDS_DEPTH>(q, stack, deep);  // no child entered: next sub-tree off the stack
     if (q.cur < 0 && q.leafPos == q.leafEnd) {  // park the leaf `cur` refers to, walk on
         const unsigned bits = ~(unsigned)q.cur;
         q.leafPos = bits >> 3;
@@ -640,8 +617,8 @@ template <int STACK, int DEEP, bool COUNT, int WAVES = PT_WAVES_PER_SIMD, bool P
 __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P, DevScene S, Images img, DevCounters* counters)
 {
     static_assert(kMegaThreads == 64, "one wave per block: the sample pool below is wave-wide");
-    __shared__ int s_stack[(STACK + PT_WIDE_NODES) * kMegaThreads];  // (wide nodes: a spare row for the push that is not one)
-    int deepStack[DEEP > 0 ? DEEP : 1];
+    __shared__ int s_stack[(STACK + 1) * kMegaThreads];  // (a spare row for the push that is not one)
+    int deepStack[DEEP + 1];
     __shared__ unsigned s_pixel[64];  // the tile's pixels that lie inside the image, compacted
     __shared__ unsigned s_depth[COUNT ? 32 : 1];  // counting build: closest-hit queries by path depth
     const unsigned lane = threadIdx.x;
@@ -1036,7 +1013,7 @@ template <int STACK, bool COUNT>
 __global__ __launch_bounds__(kBlockThreads) void traverseKernel(DevParams P, DevScene S, WfState W, Images img, WfQueues Q,
                                                                DevCounters* counters)
 {
-    __shared__ int s_stack[STACK * kBlockThreads];
+    __shared__ int s_stack[(STACK + 1) * kBlockThreads];  // (a spare row for the push that is not one)
     // finished extension queries wait here until a full wave's worth can be appended to the shade
     // queue with one atomic (a contended global counter per finished ray would stall every step)
     __shared__ unsigned s_done[kBlockThreads / 64][128];

@@ -201,38 +201,58 @@ float4* imagePtr(pt_ctx* c, int which) { return c->bound[which] ? c->bound[which
 
 int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count);
 
-// Folds every other level of the binary tree in dNodes away: dNodes4, level by level from the root.
+// Makes the four-wide tree the kernels walk (dNodes4) of the binary one in dNodes, level by level from the root,
+// and drops the binary one.  A query's stack holds at most three entries per level of the wide tree.
+constexpr int kStackLds = 48;      // megakernel: entries in LDS ...
+constexpr int kStackPrivate = 48;  // ... and, for deeper trees, in lane-private memory
+constexpr int kStackWavefront = 63;  // wavefront pipeline: all in LDS (64 rows of 256 lanes = the 64 KB a block may have)
 int collapseTree(pt_ctx* c, size_t nodeCount)
 {
     c->wideLevels = 0;
+    c->nodeBytes = 2 * sizeof(DevNode4);
     HIP_TRY(c->dNodes4.ensure((nodeCount + 2) * sizeof(DevNode4)));
-    HIP_TRY(hipMemsetAsync(c->dNodes4.ptr, 0, 2 * sizeof(DevNode4), c->stream));
-    if (c->rootRef <= 0) return PT_OK;  // the root is a leaf
+    HIP_TRY(hipMemsetAsync(c->dNodes4.ptr, 0, 2 * sizeof(DevNode4), c->stream));  // node 0: idle lanes fetch it
+    if (c->rootRef <= 0) {  // the root is a leaf
+        c->dNodes.release();
+        return PT_OK;
+    }
+    if ((nodeCount + 2) * sizeof(DevNode4) >= (1ull << 32))
+        return fail(PT_ERR_SCENE, "node array of 4 GB or more (the kernels address records by 32-bit byte offsets)");
     DeviceBuffer frontier[2], counters;
     HIP_TRY(frontier[0].ensure(nodeCount * sizeof(int2)));
     HIP_TRY(frontier[1].ensure(nodeCount * sizeof(int2)));
     HIP_TRY(counters.ensure(8));
-    const int2 root = make_int2(c->rootRef, 1);
-    unsigned h[2] = {2u, 0u};  // next free wide node (0: the dummy, 1: the root); size of the next frontier
-    HIP_TRY(hipMemcpyAsync(frontier[0].ptr, &root, sizeof(root), hipMemcpyHostToDevice, c->stream));
-    unsigned count = 1;
-    int cur = 0;
-    while (count > 0) {
-        HIP_TRY(hipMemcpyAsync(counters.ptr, h, 8, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(collapseKernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, (const DevNode*)c->dNodes.ptr,
-                           (DevNode4*)c->dNodes4.ptr, (const int2*)frontier[cur].ptr, count, (int2*)frontier[cur ^ 1].ptr,
-                           (unsigned*)counters.ptr);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h, counters.ptr, 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        count = h[1];
-        h[1] = 0;
-        cur ^= 1;
-        c->wideLevels++;
+    unsigned wideCount = 0;
+    // by surface area first; should that leave the tree deeper than the stacks hold, both children of every node are
+    // opened instead, which at least halves the binary tree's depth (at most 64)
+    for (int uniform = 0; uniform < 2; uniform++) {
+        const int2 root = make_int2(c->rootRef, 1);
+        unsigned h[2] = {2u, 0u};  // next free wide node (0: the dummy, 1: the root); size of the next frontier
+        HIP_TRY(hipMemcpyAsync(frontier[0].ptr, &root, sizeof(root), hipMemcpyHostToDevice, c->stream));
+        unsigned count = 1;
+        int cur = 0, levels = 0;
+        while (count > 0) {
+            HIP_TRY(hipMemcpyAsync(counters.ptr, h, 8, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(collapseKernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, (const DevNode*)c->dNodes.ptr,
+                               (DevNode4*)c->dNodes4.ptr, (const int2*)frontier[cur].ptr, count, (int2*)frontier[cur ^ 1].ptr,
+                               (unsigned*)counters.ptr, uniform);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(h, counters.ptr, 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            count = h[1];
+            h[1] = 0;
+            cur ^= 1;
+            levels++;
+        }
+        c->wideLevels = levels;
+        wideCount = h[0];
+        if (3 * levels <= kStackLds + kStackPrivate) break;
     }
-    frontier[0].release();
-    frontier[1].release();
-    counters.release();
+    if (3 * c->wideLevels > kStackLds + kStackPrivate)
+        return fail(PT_ERR_SCENE, "BVH too deep: " + std::to_string(c->wideLevels) + " levels of four-wide nodes, the traversal stack holds " +
+                                      std::to_string((kStackLds + kStackPrivate) / 3));
+    c->nodeBytes = (size_t)wideCount * sizeof(DevNode4);
+    c->dNodes.release();
     return PT_OK;
 }
 
@@ -282,10 +302,9 @@ int syncScene(pt_ctx* c)
         c->rootRef = packed.rootRef;
         c->maxDepth = packed.maxDepth;
         {
-            const int rcw = collapseTree(c, packed.nodes.size());
+            const int rcw = collapseTree(c, packed.nodes.size());  // sets nodeBytes
             if (rcw != PT_OK) return rcw;
         }
-        c->nodeBytes = nb;
         c->triangleBytes = tb;
         c->shadingBytes = sb;
         c->geometryDirty = false;
@@ -399,7 +418,10 @@ int wavefrontDispatch(pt_ctx* c, const DevParams& P, const DevScene& S, const Im
     WfCtrl* ctrl = (WfCtrl*)c->dCtrl.ptr;
     unsigned* rayQ[2] = {(unsigned*)c->dRayQ[0].ptr, (unsigned*)c->dRayQ[1].ptr};
     const dim3 block(kBlockThreads);
-    const bool deep = c->maxDepth > 32;
+    if (3 * c->wideLevels > kStackWavefront)
+        return fail(PT_ERR_SCENE, "BVH too deep for the wavefront pipeline (" + std::to_string(c->wideLevels) +
+                                      " levels of four-wide nodes, its stack holds " + std::to_string(kStackWavefront / 3) + "): use the megakernel");
+    const bool deep = 3 * c->wideLevels > 32;
 
     hipLaunchKernelGGL(wfResetKernel, dim3(1), dim3(1), 0, c->stream, ctrl);
     hipLaunchKernelGGL(wfStartKernel, dim3((unsigned)((pixels + kBlockThreads - 1) / kBlockThreads)), block, 0, c->stream, P, W,
@@ -422,12 +444,12 @@ int wavefrontDispatch(pt_ctx* c, const DevParams& P, const DevScene& S, const Im
         const dim3 tgrid((unsigned)c->traverseBlocks);
         if (counted) {
             if (deep)
-                hipLaunchKernelGGL((traverseKernel<64, true>), tgrid, block, 0, c->stream, P, S, W, img, Q, ctr);
+                hipLaunchKernelGGL((traverseKernel<kStackWavefront, true>), tgrid, block, 0, c->stream, P, S, W, img, Q, ctr);
             else
                 hipLaunchKernelGGL((traverseKernel<32, true>), tgrid, block, 0, c->stream, P, S, W, img, Q, ctr);
         } else {
             if (deep)
-                hipLaunchKernelGGL((traverseKernel<64, false>), tgrid, block, 0, c->stream, P, S, W, img, Q, ctr);
+                hipLaunchKernelGGL((traverseKernel<kStackWavefront, false>), tgrid, block, 0, c->stream, P, S, W, img, Q, ctr);
             else
                 hipLaunchKernelGGL((traverseKernel<32, false>), tgrid, block, 0, c->stream, P, S, W, img, Q, ctr);
         }
@@ -509,25 +531,26 @@ void launchTrace(const pt_ctx* c, hipStream_t st, const DevParams& P, const DevS
                  bool counted, bool pull)
 {
     const dim3 block(kMegaThreads);
-    // Trees up to 32 levels deep keep the whole traversal stack in LDS (8 KB per wave).  Deeper
-    // ones keep 32 entries there and the rest in private memory (3 % slower than an all-LDS kernel
-    // on a 5 M-triangle scene whose tree is 34 deep; a 40-entry LDS stack costs 6 %, a 48-entry one 13 %).
-    const bool deep = PT_WIDE_NODES ? 3 * c->wideLevels > 48 : c->maxDepth > 32;
+    // A query's stack holds at most three entries per level of the four-wide tree.  Up to 48 entries it lives in
+    // LDS (12.5 KB per wave, which twelve resident waves per CU still fit); deeper trees keep 48 entries there
+    // and the rest in lane-private memory, which very few rays touch.
+    const bool deep = 3 * c->wideLevels > kStackLds;
     // Three waves per SIMD (168 VGPRs, next to nothing spilled) unless four are asked for (128 VGPRs, some 70
     // values spilled in the shading blocks): three are 2 % faster on the reference's tree of the benchmark scene
     // and 10 % faster on the trees of this library's own builders, where shading weighs more.
     const bool three = c->wavesPerSimd != 4;
-#define PT_LAUNCH_TRACE(STACK_DEEP, COUNTED, WAVES, PULL) \
-    hipLaunchKernelGGL((renderKernel<(PT_WIDE_NODES ? 48 : 32), STACK_DEEP, COUNTED, WAVES, PULL>), grid, block, 0, st, P, S, img, ctr)
-#define PT_LAUNCH_TRACE_4(STACK_DEEP, COUNTED)                            \
-    do {                                                                  \
-        if (three && pull) PT_LAUNCH_TRACE(STACK_DEEP, COUNTED, 3, true); \
-        else if (three) PT_LAUNCH_TRACE(STACK_DEEP, COUNTED, 3, false);   \
-        else if (pull) PT_LAUNCH_TRACE(STACK_DEEP, COUNTED, 4, true);     \
-        else PT_LAUNCH_TRACE(STACK_DEEP, COUNTED, 4, false);              \
+#define PT_LAUNCH_TRACE(STACK_LDS, STACK_DEEP, COUNTED, WAVES, PULL) \
+    hipLaunchKernelGGL((renderKernel<STACK_LDS, STACK_DEEP, COUNTED, WAVES, PULL>), grid, block, 0, st, P, S, img, ctr)
+    // (the four-wave variant has LDS for 32 entries per lane only: it always keeps the rest in private memory)
+#define PT_LAUNCH_TRACE_4(STACK_DEEP, COUNTED)                                       \
+    do {                                                                             \
+        if (three && pull) PT_LAUNCH_TRACE(kStackLds, STACK_DEEP, COUNTED, 3, true); \
+        else if (three) PT_LAUNCH_TRACE(kStackLds, STACK_DEEP, COUNTED, 3, false);   \
+        else if (pull) PT_LAUNCH_TRACE(32, 64, COUNTED, 4, true);                    \
+        else PT_LAUNCH_TRACE(32, 64, COUNTED, 4, false);                             \
     } while (0)
-    if (deep && counted) PT_LAUNCH_TRACE_4(32, true);
-    else if (deep) PT_LAUNCH_TRACE_4(32, false);
+    if (deep && counted) PT_LAUNCH_TRACE_4(kStackPrivate, true);
+    else if (deep) PT_LAUNCH_TRACE_4(kStackPrivate, false);
     else if (counted) PT_LAUNCH_TRACE_4(0, true);
     else PT_LAUNCH_TRACE_4(0, false);
 #undef PT_LAUNCH_TRACE_4
@@ -1789,9 +1812,8 @@ int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count)
     }
     HIP_TRY(hipStreamSynchronize(st));  // the scratch buffers die with this scope
     c->maxDepth = height;
-    c->rootRef = n > 1 ? 1 : c->rootRef;
     {
-        const int rcw = collapseTree(c, devNodeCount);
+        const int rcw = collapseTree(c, devNodeCount);  // sets nodeBytes
         if (rcw != PT_OK) return rcw;
     }
     forgetTileCosts(c);
@@ -1803,7 +1825,6 @@ int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count)
     c->deviceNodeCount = refNodeCount;
     c->devicePrimCount = count;
     c->deviceMaxMeshIndex = hb.maxMeshIndex;
-    c->nodeBytes = devNodeCount * sizeof(DevNode);
     c->triangleBytes = count * sizeof(DevTriangle);
     c->shadingBytes = count * sizeof(DevShading);
     return PT_OK;

