@@ -247,6 +247,8 @@ def main():
     ap.add_argument("--bvh", choices=["host", "full-sweep", "device"], default="host",
                     help="host: the reference's sweep-SAH builder (bit-identical tree); device: GPU builder")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-frame-by-frame", action="store_true",
+                    help="skip the extra run of 64 one-sample dispatch calls (frame_by_frame)")
     ap.add_argument("--no-device-tree", action="store_true",
                     help="skip the extra measurement on the GPU-built tree (profiling runs: one tree per kernel name)")
     ap.add_argument("--reduce-every-step", action="store_true", help="N > 1: all-reduce after every step, not once per render")
@@ -432,7 +434,7 @@ def main():
                                     "frac": resolve_bytes / avg_resolve_s / 1e9 / HBM_PEAK_GBS} if avg_resolve_s > 0 else None),
             },
         }
-        if world == 1 and not args.stub:
+        if world == 1 and not args.stub and not args.no_frame_by_frame:
             # Outside the timed region, for the record: the reference viewer's call pattern, one sample per
             # pixel per dispatch call, on the library's own stream (where consecutive calls overlap).
             try:

@@ -125,7 +125,10 @@ int pt_bind_images(pt_ctx* ctx, void* d_radiance, void* d_albedo, void* d_normal
 /* ------------------------------------------------- scene buffers (SSBO 0..3) */
 
 /* SSBO binding 2 (PathTracingRenderer.cpp:566-613): `count` BvhNodeAlign records of 48 B,
- * node 0 the dummy, root = node 1. */
+ * node 0 the dummy, root = node 1.  The tree is taken as it is: at the next dispatch it is repacked
+ * (leaves folded into child references) and folded, on the device, into the four-wide nodes the kernels
+ * walk -- the same boxes and the same leaves, so the same hits; PT_ERR_SCENE at that dispatch if the
+ * tree is more than 64 levels deep. */
 int pt_upload_nodes(pt_ctx* ctx, const void* nodes48, size_t count);
 /* SSBO binding 3 (PathTracingRenderer.cpp:615-662): BvhPrimitiveAlign records of 112 B in
  * post-build order. */
@@ -367,6 +370,10 @@ int pt_debug_get_profile(pt_ctx* ctx, uint64_t out16[16]);
  * pt_dispatch_counted() under the megakernel scheduler by path depth: [0] primary rays, [1] the rays
  * after the first bounce, ...; depths past 31 are counted in [31]. */
 int pt_debug_get_depth_histogram(pt_ctx* ctx, uint64_t out32[32]);
+/* Waves the trace kernel variant of the most recent megakernel launch keeps resident on the GPU (registers
+ * and LDS both limit it; the runtime is asked once per variant): the launch's grid when the waves pull
+ * their work items. */
+int pt_debug_get_resident_waves(pt_ctx* ctx, uint32_t* waves_out);
 /* Profiling hook (no counterpart in the reference): device wall-clock ticks at the start and end of every
  * wave of the most recent pt_dispatch_counted() under the megakernel scheduler, as (start, end) pairs
  * per block of the grid (start = 0: the block found no work); *clock_khz_out = tick rate.  NULL pairs_out

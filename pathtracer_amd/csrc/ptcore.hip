@@ -147,7 +147,9 @@ struct pt_ctx {
     bool forkDirty = true;
     bool tileOrdering = true;
     int tileSplit = -1;  // no block may cost more than 1/tileSplit of the launch's lower bound (0: never split, -1: by image size)
-    uint32_t waveSlots = 4096;  // waves the chip holds at once (CUs x SIMDs x waves per SIMD)
+    uint32_t computeUnits = 256;
+    std::vector<std::pair<void (*)(DevParams, DevScene, Images, DevCounters*), uint32_t>> residentWaves;  // per trace kernel variant
+    uint32_t lastSlots = 0;  // resident waves of the most recent megakernel launch's variant
     uint64_t sampleBudgetBytes = 8ull << 30;
     int wavesPerSimd = 0;      // megakernel variant: 3 or 4 waves per SIMD (0: the default, 3)
     bool rebuildOnUpload = false;  // pt_upload_nodes' tree is replaced by the device builder's over the same primitives
@@ -203,7 +205,7 @@ int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count);
 
 // Makes the four-wide tree the kernels walk (dNodes4) of the binary one in dNodes, level by level from the root,
 // and drops the binary one.  A query's stack holds at most three entries per level of the wide tree.
-constexpr int kStackLds = 48;      // megakernel: entries in LDS ...
+constexpr int kStackLds = 48;      // megakernel: entries in LDS (40 ... 48 measured alike: twelve waves per CU fit either way) ...
 constexpr int kStackPrivate = 48;  // ... and, for deeper trees, in lane-private memory
 constexpr int kStackWavefront = 63;  // wavefront pipeline: all in LDS (64 rows of 256 lanes = the 64 KB a block may have)
 int collapseTree(pt_ctx* c, size_t nodeCount)
@@ -525,36 +527,42 @@ void fillLaunchBlocks(const pt_ctx* c, uint32_t frameFirst, uint32_t frameCount,
     P.workNext = nullptr;
 }
 
-// Launches the trace kernel variant that fits the tree in use.  `pull`: a grid of resident waves that take
+// The trace kernel variant that fits the tree and the settings in use.  `pull`: a grid of resident waves that take
 // the work items off a counter; else one block per item.
-void launchTrace(const pt_ctx* c, hipStream_t st, const DevParams& P, const DevScene& S, const Images& img, DevCounters* ctr, dim3 grid,
-                 bool counted, bool pull)
+using TraceKernel = void (*)(DevParams, DevScene, Images, DevCounters*);
+TraceKernel traceVariant(const pt_ctx* c, bool counted, bool pull)
 {
-    const dim3 block(kMegaThreads);
     // A query's stack holds at most three entries per level of the four-wide tree.  Up to 48 entries it lives in
     // LDS (12.5 KB per wave, which twelve resident waves per CU still fit); deeper trees keep 48 entries there
     // and the rest in lane-private memory, which very few rays touch.
     const bool deep = 3 * c->wideLevels > kStackLds;
     // Three waves per SIMD (168 VGPRs, next to nothing spilled) unless four are asked for (128 VGPRs, some 70
-    // values spilled in the shading blocks): three are 2 % faster on the reference's tree of the benchmark scene
-    // and 10 % faster on the trees of this library's own builders, where shading weighs more.
+    // values spilled in the shading blocks; LDS for 32 stack entries per lane only, the rest always in private
+    // memory): three are faster on every tree measured.
     const bool three = c->wavesPerSimd != 4;
-#define PT_LAUNCH_TRACE(STACK_LDS, STACK_DEEP, COUNTED, WAVES, PULL) \
-    hipLaunchKernelGGL((renderKernel<STACK_LDS, STACK_DEEP, COUNTED, WAVES, PULL>), grid, block, 0, st, P, S, img, ctr)
-    // (the four-wave variant has LDS for 32 entries per lane only: it always keeps the rest in private memory)
-#define PT_LAUNCH_TRACE_4(STACK_DEEP, COUNTED)                                       \
-    do {                                                                             \
-        if (three && pull) PT_LAUNCH_TRACE(kStackLds, STACK_DEEP, COUNTED, 3, true); \
-        else if (three) PT_LAUNCH_TRACE(kStackLds, STACK_DEEP, COUNTED, 3, false);   \
-        else if (pull) PT_LAUNCH_TRACE(32, 64, COUNTED, 4, true);                    \
-        else PT_LAUNCH_TRACE(32, 64, COUNTED, 4, false);                             \
-    } while (0)
-    if (deep && counted) PT_LAUNCH_TRACE_4(kStackPrivate, true);
-    else if (deep) PT_LAUNCH_TRACE_4(kStackPrivate, false);
-    else if (counted) PT_LAUNCH_TRACE_4(0, true);
-    else PT_LAUNCH_TRACE_4(0, false);
-#undef PT_LAUNCH_TRACE_4
-#undef PT_LAUNCH_TRACE
+    static const TraceKernel table[2][2][3] = {
+        // [counted][pull][three waves, shallow | three waves, deep | four waves]
+        {{renderKernel<kStackLds, 0, false, 3, false>, renderKernel<kStackLds, kStackPrivate, false, 3, false>, renderKernel<32, 64, false, 4, false>},
+         {renderKernel<kStackLds, 0, false, 3, true>, renderKernel<kStackLds, kStackPrivate, false, 3, true>, renderKernel<32, 64, false, 4, true>}},
+        {{renderKernel<kStackLds, 0, true, 3, false>, renderKernel<kStackLds, kStackPrivate, true, 3, false>, renderKernel<32, 64, true, 4, false>},
+         {renderKernel<kStackLds, 0, true, 3, true>, renderKernel<kStackLds, kStackPrivate, true, 3, true>, renderKernel<32, 64, true, 4, true>}},
+    };
+    return table[counted][pull][three ? (deep ? 1 : 0) : 2];
+}
+
+// Waves of `kernel` the chip keeps resident at once (registers and LDS both count), asked of the runtime once per variant.
+int residentWaves(pt_ctx* c, TraceKernel kernel, uint32_t& waves)
+{
+    for (const auto& known : c->residentWaves)
+        if (known.first == kernel) {
+            waves = known.second;
+            return PT_OK;
+        }
+    int perCu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, kMegaThreads, 0));
+    waves = (uint32_t)std::max(1, perCu) * c->computeUnits;
+    c->residentWaves.emplace_back(kernel, waves);
+    return PT_OK;
 }
 
 // One launch (of a dispatch call's one or more) on launch lane `k`; with `overlap` its trace side goes to the
@@ -592,14 +600,18 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
         // critical path (small images, a few expensive tiles in a cheap frame).
         const size_t tiles = (size_t)P.tilesX * P.tilesY;
         if (frameCount > 65535u) return fail(PT_ERR_INVALID, "a megakernel launch takes at most 65535 frames");
-        // waves the kernel variant in use keeps resident (waveSlots counts four per SIMD and sizes the item list)
-        const uint32_t slots = c->wavesPerSimd != 4 ? c->waveSlots / 4u * 3u : c->waveSlots;
+        const bool pull = c->pullItems;
+        const TraceKernel kernel = traceVariant(c, counted, pull);
+        uint32_t slots = 0;  // waves the kernel variant in use keeps resident
+        int rcs = residentWaves(c, kernel, slots);
+        if (rcs != PT_OK) return rcs;
+        c->lastSlots = slots;
         // The cap on an item's cost is 1/split of the launch's lower bound.  Waves that pull their items lose nothing
         // at an item's end, so the cap can be fine: swept over 1, 2, 4 ... 64 with 64 frames per launch, a 32nd is 11 %
         // faster than a half at 512 x 512 and 3 % at 720p, makes no difference at 1080p, and is 4 % slower than an
         // eighth at 256 x 256, where there are fewer tiles than waves.  Unless set by hand.
         const unsigned split = c->tileSplit >= 0 ? (unsigned)c->tileSplit : (tiles < slots ? 8u : 32u);
-        const size_t capacity = tiles + (size_t)split * c->waveSlots;
+        const size_t capacity = tiles + (size_t)split * c->computeUnits * 16u;  // (sized for the most waves any variant keeps)
         if (L.tileCostTiles != tiles || L.blockCapacity != capacity) {
             for (DeviceBuffer* b : {&L.dTileCost, &L.dTileParts, &L.dTileKey, &L.dTileKeySorted, &L.dTileIds, &L.dTileOrder,
                                     &L.dPartsInOrder, &L.dBlockStart})
@@ -656,7 +668,6 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
         // The items are pulled by a grid of as many waves as the chip keeps resident (a block per item spends the end
         // of its life with idle lanes, and a launch of few samples per pixel is nothing but such ends: 1080p, benchmark
         // scene, one sample per pixel 2.5 -> 1.3 ms, 16 samples 12.1 -> 10.8 ms, 64 samples 43.7 -> 41.9 ms).
-        const bool pull = c->pullItems;
         if (pull) gridBlocks = std::min<size_t>(gridBlocks, slots);
         HIP_TRY(hipMemsetAsync(L.dTileCost.ptr, 0, (tiles + 1) * 4, st));  // waves add the ticks they spend; work counter
         L.tileCostValid = true;
@@ -668,7 +679,7 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
         }
         const dim3 grid((unsigned)gridBlocks);
         HIP_TRY(hipEventRecord(c->evTrace0, st));
-        launchTrace(c, st, P, S, img, ctr, grid, counted, pull);
+        hipLaunchKernelGGL(kernel, grid, dim3(kMegaThreads), 0, st, P, S, img, ctr);
         HIP_TRY(hipEventRecord(c->evTrace1, st));
         if (overlap) {
             HIP_TRY(hipEventRecord(L.evTraced, st));
@@ -762,7 +773,7 @@ int pt_create(int device, int width, int height, pt_ctx** out)
     c->device = device;
     c->width = width;
     c->height = height;
-    c->waveSlots = (uint32_t)std::max(1, prop.multiProcessorCount) * 4u * PT_WAVES_PER_SIMD;
+    c->computeUnits = (uint32_t)std::max(1, prop.multiProcessorCount);
     HIP_TRY(hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking));
     c->stream = c->ownStream;
     HIP_TRY(hipEventCreate(&c->evStart));
@@ -1287,8 +1298,11 @@ int pt_dispatch_static(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint
     Images img{imagePtr(c, 0), imagePtr(c, 1), imagePtr(c, 2)};
     HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(DevCounters), c->stream));
     HIP_TRY(hipMemsetAsync(base, 0, costBytes, c->stream));  // the array keeps the previous call's contents
-    const uint32_t slots = c->wavesPerSimd != 4 ? c->waveSlots / 4u * 3u : c->waveSlots;
-    launchTrace(c, c->stream, P, S, img, ctr, dim3((unsigned)std::min<size_t>(tiles, slots)), false, true);
+    const TraceKernel kernel = traceVariant(c, false, true);
+    uint32_t slots = 0;
+    const int rcs = residentWaves(c, kernel, slots);  // (asks the runtime about the kernel on first use; allocates nothing on the device)
+    if (rcs != PT_OK) return rcs;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)std::min<size_t>(tiles, slots)), dim3(kMegaThreads), 0, c->stream, P, S, img, ctr);
     hipLaunchKernelGGL(resolveKernel, dim3((unsigned)((P.pixels + 255) / 256)), dim3(256), 0, c->stream, P, img);
     HIP_TRY(hipGetLastError());
     c->timed = false;  // no events around this launch
@@ -1512,6 +1526,16 @@ int pt_debug_set_tuning(pt_ctx* c, int key, int value)
         return PT_OK;
     default: return fail(PT_ERR_INVALID, "unknown tuning key");
     }
+}
+
+// Waves the trace kernel variant of the most recent megakernel launch keeps resident on the chip (its grid when
+// the waves pull their items).
+int pt_debug_get_resident_waves(pt_ctx* c, uint32_t* wavesOut)
+{
+    if (!c || !wavesOut) return fail(PT_ERR_INVALID, "null argument");
+    if (!c->lastSlots) return fail(PT_ERR_STATE, "no megakernel launch yet");
+    *wavesOut = c->lastSlots;
+    return PT_OK;
 }
 
 // Profiling hook: wall-clock ticks at the start and the end of every wave of the most recent

@@ -208,6 +208,12 @@ class Renderer:
         check(self._lib.pt_read_display(self._h, float(exposure), _ptr(out)))
         return out
 
+    def resident_waves(self):
+        """Waves the most recent megakernel launch's kernel variant keeps resident on the GPU."""
+        n = ctypes.c_uint32()
+        check(self._lib.pt_debug_get_resident_waves(self._h, ctypes.byref(n)))
+        return n.value
+
     def debug_view(self, view):
         """The reference shader's DEBUG_ENABLED output into the radiance image: 1 = BVH heat map, 2 = HDRI
         sampling cache.  Returns the (height, width, 4) float32 image."""

@@ -37,6 +37,7 @@ g.dispatch(1, spp, 1, counted=True)
 g.synchronize()
 st, pr = g.stats(), g.profile()
 rays = st.rays_closest + st.rays_any
+print(f"resident waves of the kernel variant: {g.resident_waves()}")
 print(f"rays {rays}  node visits/ray {st.node_visits / rays:.2f}  tri tests/ray {st.triangle_tests / rays:.2f}  ms {g.last_dispatch_ms():.2f}")
 print(f"traversal iterations {pr[0]}  avg lanes traversing {pr[1] / pr[0]:.1f}")
 print(f"  with node step   {pr[2]} ({pr[2] / pr[0]:.2%})  avg lanes {pr[3] / max(pr[2], 1):.1f}")

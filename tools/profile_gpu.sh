@@ -4,7 +4,7 @@
 #   tools/profile_gpu.sh <tag> [bench args...]
 set -u
 TAG=${1:-run}; shift || true
-ARGS=${*:-"--steps 2 --warmup 1 --no-cpu-baseline --no-device-tree"}
+ARGS=${*:-"--steps 2 --warmup 1 --no-cpu-baseline --no-device-tree --no-frame-by-frame"}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
