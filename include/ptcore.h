@@ -370,6 +370,10 @@ int pt_debug_get_profile(pt_ctx* ctx, uint64_t out16[16]);
  * pt_dispatch_counted() under the megakernel scheduler by path depth: [0] primary rays, [1] the rays
  * after the first bounce, ...; depths past 31 are counted in [31]. */
 int pt_debug_get_depth_histogram(pt_ctx* ctx, uint64_t out32[32]);
+/* The four-wide tree the kernels walk (made of the uploaded or device-built binary tree at the first dispatch
+ * after it changed): its depth in levels, and whether it was folded level by level (1) because folding by
+ * surface area had left it deeper than the traversal stacks hold (32 levels). */
+int pt_debug_get_tree_info(pt_ctx* ctx, uint32_t* levels_out, uint32_t* level_by_level_out);
 /* Waves the trace kernel variant of the most recent megakernel launch keeps resident on the GPU (registers
  * and LDS both limit it; the runtime is asked once per variant): the launch's grid when the waves pull
  * their work items. */

@@ -114,6 +114,7 @@ struct pt_ctx {
     // device side
     DeviceBuffer dNodes4;
     int wideLevels = 0;
+    bool foldedLevelByLevel = false;  // folding by surface area left the tree too deep
     DeviceBuffer dNodes, dTriangles, dShading, dMaterials, dTextures, dTexels, dSrgbLut, dEnvColorPdf, dEnvSample;
     DeviceBuffer dImages[3];
     DeviceBuffer dCounters[kLaunchLanes];  // one set per launch lane (a call's launches may still run when the next calls start)
@@ -247,6 +248,7 @@ int collapseTree(pt_ctx* c, size_t nodeCount)
             levels++;
         }
         c->wideLevels = levels;
+        c->foldedLevelByLevel = uniform != 0;
         wideCount = h[0];
         if (3 * levels <= kStackLds + kStackPrivate) break;
     }
@@ -1526,6 +1528,16 @@ int pt_debug_set_tuning(pt_ctx* c, int key, int value)
         return PT_OK;
     default: return fail(PT_ERR_INVALID, "unknown tuning key");
     }
+}
+
+// The four-wide tree in use: its depth in levels, and whether it had to be folded level by level (1) because folding
+// by surface area left it deeper than the traversal stacks hold.  Valid after a dispatch or a device build.
+int pt_debug_get_tree_info(pt_ctx* c, uint32_t* levelsOut, uint32_t* levelByLevelOut)
+{
+    if (!c || !levelsOut || !levelByLevelOut) return fail(PT_ERR_INVALID, "null argument");
+    *levelsOut = (uint32_t)c->wideLevels;
+    *levelByLevelOut = c->foldedLevelByLevel ? 1u : 0u;
+    return PT_OK;
 }
 
 // Waves the trace kernel variant of the most recent megakernel launch keeps resident on the chip (its grid when

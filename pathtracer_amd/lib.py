@@ -128,6 +128,7 @@ SYMBOLS = {
     "pt_read_display": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]),
     "pt_debug_view": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pt_debug_get_resident_waves": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]),
+    "pt_debug_get_tree_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
     "pt_get_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Stats)]),
     "pt_last_dispatch_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
     "pt_last_kernel_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),

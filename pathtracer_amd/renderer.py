@@ -208,6 +208,12 @@ class Renderer:
         check(self._lib.pt_read_display(self._h, float(exposure), _ptr(out)))
         return out
 
+    def tree_info(self):
+        """(levels of the four-wide tree in use, folded level by level instead of by surface area)."""
+        a, b = ctypes.c_uint32(), ctypes.c_uint32()
+        check(self._lib.pt_debug_get_tree_info(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, bool(b.value)
+
     def resident_waves(self):
         """Waves the most recent megakernel launch's kernel variant keeps resident on the GPU."""
         n = ctypes.c_uint32()

@@ -572,6 +572,80 @@ def _chain_tree(levels):
     return nodes.view(np.float32), prims
 
 
+def _caterpillar_tree(levels):
+    """A path of `levels` interior nodes whose every node has, beside the next path node, a sibling sub-tree
+    (two interior nodes over four one-triangle leaves) with larger boxes than the path's.  Folding by surface
+    area opens the sibling and its two children at every step and never the path node, so the four-wide
+    tree is as deep as the path: deeper than the traversal stack allows, which makes the library fold the
+    tree again with both children of every node opened."""
+    verts, idx = [], []
+
+    def tri(x):
+        k = len(idx) // 3
+        verts.extend([[x, -1, -1, -1, 0, 0, 0, 0], [x, -1, 1, -1, 0, 0, 0, 1], [x, 1, -1, -1, 0, 0, 1, 0]])
+        idx.extend([3 * k, 3 * k + 1, 3 * k + 2])
+        return k
+
+    count = 8 * levels + 2
+    nodes = np.zeros((count, 10), np.int32)
+    boxes = nodes.view(np.float32)
+
+    def box(node, lo, hi):
+        boxes[node, 4:7] = lo
+        boxes[node, 7:10] = hi
+
+    def leaf(node, x):
+        nodes[node, 2], nodes[node, 3] = 1, tri(x)
+        box(node, (x, -1, -1), (x, 1, 1))
+
+    for j in range(levels):
+        me = 1 + 8 * j
+        sib = me + 1
+        nodes[me, 0], nodes[me, 1] = sib, me + 8  # left: the sibling sub-tree, right: the next path node (or the last leaf)
+        box(me, (-20, -20, -20), (20, 20, 20))
+        box(sib, (-19, -19, -19), (19, 19, 19))
+        nodes[sib, 0], nodes[sib, 1] = sib + 1, sib + 4
+        for half in (sib + 1, sib + 4):
+            box(half, (-18, -18, -18), (18, 18, 18))
+            nodes[half, 0], nodes[half, 1] = half + 1, half + 2
+            leaf(half + 1, 0.01 * (4 * j + (0 if half == sib + 1 else 2)))
+            leaf(half + 2, 0.01 * (4 * j + (1 if half == sib + 1 else 3)))
+    # path boxes: smaller than every sibling box (which is what keeps them closed), still around all triangles
+    for j in range(1, levels):
+        box(1 + 8 * j, (-2, -2, -2), (0.01 * 4 * levels + 2, 2, 2))
+    leaf(1 + 8 * levels, 0.01 * 4 * levels)
+    prims = R.assemble_primitives(np.array(verts, np.float32), np.array(idx, np.uint32), 0)
+    return nodes.view(np.float32), prims
+
+
+def test_tree_whose_fold_by_area_is_too_deep_is_folded_level_by_level():
+    levels = 60
+    nodes40, prims = _caterpillar_tree(levels)
+    mats = np.array([scenes.material(albedo=(0.7, 0.6, 0.5), roughness=0.6)], dtype=scenes.MATERIAL_DTYPE)
+    hdri, cache = environment(256, 128)
+    sorted_prims, sah_nodes = R.build_bvh_sah(prims.copy(), 4)
+    images = {}
+    for name, (n40, p100) in {"caterpillar": (nodes40, prims), "sah": (sah_nodes, sorted_prims)}.items():
+        g = R.Renderer(96, 64)
+        g.upload_nodes(R.align_nodes(n40))
+        g.upload_primitives(R.align_primitives(p100))
+        g.upload_materials(mats)
+        g.upload_environment(hdri, cache)
+        g.set_params(R.default_params(96, 64))
+        g.clear()
+        g.dispatch(1, 3, 1, counted=True)
+        images[name] = [g.read_image(k) for k in range(3)]
+        levels_wide, level_by_level = g.tree_info()
+        if name == "caterpillar":
+            assert level_by_level and 16 < levels_wide <= 32, (levels_wide, level_by_level)
+            assert 16 < g.stats().max_stack_depth <= 96
+        else:
+            assert not level_by_level and levels_wide <= 16
+    for k in range(3):
+        assert images["caterpillar"][k].tobytes() == images["sah"][k].tobytes()
+    assert np.any(images["caterpillar"][0][..., :3] > 0)
+
+
 def test_four_wave_kernel_and_scheduler_thresholds_give_the_same_image():
     """The 4-waves-per-SIMD build of the megakernel (A/B variant), one block per work item instead of waves
     that pull the items, and other phase thresholds change the schedule, not a bit of the result."""
