@@ -215,12 +215,16 @@ __global__ void collapseKernel(const DevNode* __restrict__ in, DevNode4* __restr
         if (pick < 0) break;
         open(pick);
     }
+    // the interior entries get wide nodes of their own in the next level, side by side
+    int interior = 0;
+    for (int k = 0; k < used; k++) interior += ref[k] > 0;
+    int dst = interior ? (int)atomicAdd(&counters[0], (unsigned)interior) : 0;
+    int at = interior ? (int)atomicAdd(&counters[1], (unsigned)interior) : 0;
     for (int k = 0; k < used; k++) {
         int r = ref[k];
-        if (r > 0) {  // an interior node: it gets a wide node of its own in the next level
-            const int dst = (int)atomicAdd(&counters[0], 1u);
-            next[atomicAdd(&counters[1], 1u)] = make_int2(r, dst);
-            r = dst;
+        if (r > 0) {
+            next[at++] = make_int2(r, dst);
+            r = dst++;
         }
         w.child[k] = r;
         for (int a = 0; a < 3; a++) w.lo[a][k] = mn[k][a], w.hi[a][k] = mx[k][a];
@@ -258,10 +262,12 @@ PT_DEV int queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc, 
         const bool h1 = hitAabb(q.ro, q.inv, lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, d1, e1) & !(e1 > limit);
         const bool h2 = hitAabb(q.ro, q.inv, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, d2, e2) & !(e2 > limit);
         const bool h3 = hitAabb(q.ro, q.inv, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, d3, e3) & !(e3 > limit);
-        // The children entered, nearest first by the shader's box distance (intersection.glsl:169-180 orders its
-        // two children by the same value), through a sorting network over (distance, reference) pairs in which a
-        // child not entered is the farthest: the nearest is visited next, the others wait on the stack, the
-        // farthest lowest.  A push that is not one writes the row above the stack's top, which nothing reads.
+        // The nearest child entered, by the shader's box distance (intersection.glsl:169-180 orders its two children
+        // by the same value), is visited next and the others wait on the stack.  Three comparators over (distance,
+        // reference) pairs, in which a child not entered is the farthest, bring the nearest to the front and leave
+        // the rest half ordered (the larger of each first pair behind the smaller); finishing the sorting network
+        // (two more comparators) visits no fewer nodes and costs 2 % on the reference's tree.  A push that is not one
+        // writes the row above the stack's top, which nothing reads.
         float k0 = h0 ? d0 : kFltMax, k1 = h1 ? d1 : kFltMax, k2 = h2 ? d2 : kFltMax, k3 = h3 ? d3 : kFltMax;
         int r0 = h0 ? kids.x : 0, r1 = h1 ? kids.y : 0, r2 = h2 ? kids.z : 0, r3 = h3 ? kids.w : 0;
 #define PT_CSWAP(ka, ra, kb, rb)       \
@@ -277,8 +283,6 @@ PT_DEV int queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc, 
         PT_CSWAP(k0, r0, k1, r1)
         PT_CSWAP(k2, r2, k3, r3)
         PT_CSWAP(k0, r0, k2, r2)
-        PT_CSWAP(k1, r1, k3, r3)
-        PT_CSWAP(k1, r1, k2, r2)
 #undef PT_CSWAP
         const bool p3 = r3 != 0, p2 = r2 != 0, p1 = r1 != 0;
         stackPut<STRIDE, LDS_DEPTH>(stack, deep, q.sp, q.top);
