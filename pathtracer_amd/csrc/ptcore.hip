@@ -291,7 +291,7 @@ int syncScene(pt_ctx* c)
             return syncScene(c);
         }
         if (packed.maxDepth > 64)
-            return fail(PT_ERR_SCENE, "BVH is " + std::to_string(packed.maxDepth) + " interior levels deep; the traversal stack holds 64");
+            return fail(PT_ERR_SCENE, "BVH is " + std::to_string(packed.maxDepth) + " interior levels deep; at most 64 are taken");
         const size_t nb = packed.nodes.size() * sizeof(DevNode), tb = packed.triangles.size() * sizeof(DevTriangle),
                      sb = packed.shading.size() * sizeof(DevShading);
         if (nb >= (1ull << 32) || tb >= (1ull << 32))
@@ -1825,7 +1825,7 @@ int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count)
         devNodeCount = 1 + (size_t)tail[2] + tail[3];
         if (height > 64)
             return fail(PT_ERR_SCENE, "the device-built BVH is " + std::to_string(height) +
-                                          " levels deep; the traversal stack holds 64 (use the host builder)");
+                                          " levels deep; at most 64 are taken (use the host builder)");
         HIP_TRY(c->dRefNodes.ensure(refNodeCount * sizeof(RefNodeAlign)));
         HIP_TRY(c->dNodes.ensure(devNodeCount * sizeof(DevNode)));
         HIP_TRY(hipMemsetAsync(c->dRefNodes.ptr, 0, sizeof(RefNodeAlign), st));
