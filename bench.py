@@ -42,10 +42,10 @@ MALL_GATHER_GBS = 8600.0  # measured ceiling for random rows served by the Infin
 # triangles.  The bunny (144 k) subdivided once (576 k) is the closest stand-in at hand.
 DEFAULT_SUBDIVIDE = 1
 # Canonical record sizes for algorithmic bytes per ray: one four-wide node (4 AABBs + 4 refs),
-# one triangle (3 vertices padded), shading record, material record; one 48-byte record
-# (radiance, albedo, normal as three float4) per finished sample; 96 B of image traffic (three
+# one triangle (3 vertices padded), shading record, material record; one 36-byte record
+# (radiance, albedo, normal: three floats each) per finished sample; 96 B of image traffic (three
 # RGBA32F texels read + written) per pixel and launch.
-S_NODE, S_TRI, S_SHADE, S_MAT, S_SAMPLE, S_ACC = 128, 48, 64, 80, 48, 96
+S_NODE, S_TRI, S_SHADE, S_MAT, S_SAMPLE, S_ACC = 128, 48, 64, 80, 36, 96
 
 SCENES = {  # name -> (metric label, default width, height, bounces)
     "dragonglass": ("1080p DragonGlass", 1920, 1080, 8),
@@ -306,7 +306,7 @@ def main():
     st = g.stats()
     rays_step = st.rays_closest + st.rays_any
     bytes_per_ray = (st.node_visits * S_NODE + st.triangle_tests * S_TRI + st.closest_hits * (S_SHADE + S_MAT)) / rays_step
-    # the trace kernel writes one 48-byte record per finished sample; the resolve kernel reads the
+    # the trace kernel writes one 36-byte record per finished sample; the resolve kernel reads the
     # records back and updates the three images once per launch (16 B read + 16 B written each)
     bytes_per_launch = bytes_per_ray * rays_step + st.samples * S_SAMPLE
     resolve_bytes = st.samples * S_SAMPLE + W * H * S_ACC

@@ -285,7 +285,7 @@ int pt_dispatch_counted(pt_ctx* ctx, uint32_t frame_first, uint32_t frame_count,
  * bit-identical images, but nothing is allocated, freed, uploaded or timed: the sample records of the
  * launch and the per-tile cost words live in a static device array of PT_STATIC_SCRATCH_BYTES that every
  * GPU the library runs on holds until the process ends, and tiles launch in row-major order (no launch
- * plan).  PT_ERR_INVALID when 256 + 48 bytes x width x height x frame_count (+ 4 per 8x8 tile) exceed the
+ * plan).  PT_ERR_INVALID when 256 + 36 bytes x width x height x frame_count (+ 4 per 8x8 tile) exceed the
  * array: dispatch fewer frames per call.  PT_ERR_STATE when scene buffers or textures changed since the
  * last pt_dispatch (which uploads them), or under the wavefront scheduler.  All contexts on one GPU share
  * the array: calls that overlap on one GPU (different streams or threads) race. */
@@ -348,7 +348,7 @@ int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, 
  * split: a tile whose cost exceeds 1/value of the launch's lower bound (total cost / resident waves) has
  * its samples spread over several blocks; 0 = one block per tile; -1 (default) = 2 for images with no
  * more tiles than resident waves, else 1;
- * 8: budget of the megakernel's sample buffer in MiB (48 bytes per sample and pixel; a dispatch is cut
+ * 8: budget of the megakernel's sample buffer in MiB (36 bytes per sample and pixel; a dispatch is cut
  * into launches that fit; default 8192); 9: megakernel run by a grid of resident waves that pull the work
  * items off a counter (1, the default) or by one block per work item (0); 10: device
  * BVH builder: clusters searched on either side per round (default 32; 0 = Morton radix tree instead);

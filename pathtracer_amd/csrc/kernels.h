@@ -517,6 +517,12 @@ PT_DEV float4 accumulate(float4 prev, v3 x, float weight, unsigned mode)
     return make_float4(prev.x + x.x, prev.y + x.y, prev.z + x.z, prev.w + 1.0f);
 }
 
+// One finished sample in the sample buffer.
+struct SampleRecord {
+    v3 radiance, albedo, normal;
+};
+static_assert(sizeof(SampleRecord) == kSampleBytes, "the host sizes the sample buffer with kSampleBytes");
+
 struct Images {
     float4* radiance;
     float4* albedo;
@@ -759,10 +765,10 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
         if (COUNT) prof[10] += (unsigned)__popcll(__ballot(mode == kModeFinish));
         if (mode == kModeFinish) {
             const unsigned px = pixel & 0xffffu, py = pixel >> 16;
-            float4* rec = reinterpret_cast<float4*>(P.samples) + ((size_t)ps.k * P.pixels + ((size_t)py * P.width + px)) * 3u;
-            rec[0] = make_float4(ps.radiance.x, ps.radiance.y, ps.radiance.z, 0.0f);
-            rec[1] = make_float4(ps.albedoRes.x, ps.albedoRes.y, ps.albedoRes.z, 0.0f);
-            rec[2] = make_float4(ps.normalRes.x, ps.normalRes.y, ps.normalRes.z, 0.0f);
+            SampleRecord* rec = reinterpret_cast<SampleRecord*>(P.samples) + ((size_t)ps.k * P.pixels + ((size_t)py * P.width + px));
+            rec->radiance = ps.radiance;
+            rec->albedo = ps.albedoRes;
+            rec->normal = ps.normalRes;
             mode = kModeNew;
         }
         // lanes without a sample take the next (pixel, sample) pairs of the pool, and of the next item
@@ -886,19 +892,18 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
 
 // Folds the sample buffer into the images: one thread per pixel applies its samples in FrameCount
 // order with the shader's accumulation expression (pathtracing.comp:248-260), i.e. the same
-// rounding sequence as frame-by-frame dispatches.  Streams frameCount x 48 B per pixel, coalesced.
+// rounding sequence as frame-by-frame dispatches.  Streams frameCount x 36 B per pixel, coalesced.
 __global__ void resolveKernel(DevParams P, Images img)
 {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P.pixels) return;
     float4 r = img.radiance[p], a = img.albedo[p], n = img.normal[p];
     for (unsigned k = 0; k < P.frameCount; k++) {
-        const float4* rec = reinterpret_cast<const float4*>(P.samples) + ((size_t)k * P.pixels + p) * 3u;
-        const float4 xr = rec[0], xa = rec[1], xn = rec[2];
+        const SampleRecord rec = reinterpret_cast<const SampleRecord*>(P.samples)[(size_t)k * P.pixels + p];
         const float weight = 1.0f / (float)(P.frameFirst + k * P.frameStride);
-        r = accumulate(r, mk3(xr.x, xr.y, xr.z), weight, P.accumulateMode);
-        a = accumulate(a, mk3(xa.x, xa.y, xa.z), weight, P.accumulateMode);
-        n = accumulate(n, mk3(xn.x, xn.y, xn.z), weight, P.accumulateMode);
+        r = accumulate(r, rec.radiance, weight, P.accumulateMode);
+        a = accumulate(a, rec.albedo, weight, P.accumulateMode);
+        n = accumulate(n, rec.normal, weight, P.accumulateMode);
     }
     img.radiance[p] = r;
     img.albedo[p] = a;

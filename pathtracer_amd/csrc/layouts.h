@@ -94,6 +94,9 @@ struct alignas(64) DevNode {
 };
 static_assert(sizeof(DevNode) == 64, "");
 
+// Bytes of one finished sample's record in the megakernel's sample buffer (radiance, albedo, normal: three floats each).
+constexpr unsigned kSampleBytes = 36;
+
 // Four-wide node: the boxes of up to four children, bound by bound, and their references (0 = empty slot).
 struct alignas(128) DevNode4 {
     float lo[3][4];

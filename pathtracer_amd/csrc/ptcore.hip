@@ -133,7 +133,7 @@ struct pt_ctx {
         DeviceBuffer dPartsInOrder, dBlockStart, dBlockList, dBlockCount, dScanTemp;
         size_t tileCostTiles = 0, tileSortBytes = 0, scanBytes = 0, blockCapacity = 0;
         bool tileCostValid = false;
-        // finished samples of one launch, 48 B per (sample, pixel); resolved into the images after the launch
+        // finished samples of one launch, 36 B per (sample, pixel); resolved into the images after the launch
         DeviceBuffer dSamples;
         hipStream_t stream = nullptr;    // traces of overlapping calls
         hipEvent_t evTraced = nullptr;   // on `stream`, behind the trace kernel
@@ -637,7 +637,7 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
             L.tileCostTiles = tiles;
             L.blockCapacity = capacity;
         }
-        HIP_TRY(L.dSamples.ensure((size_t)frameCount * (size_t)c->width * c->height * 48u));
+        HIP_TRY(L.dSamples.ensure((size_t)frameCount * (size_t)c->width * c->height * kSampleBytes));
         P.samples = (float*)L.dSamples.ptr;
         P.pixels = (unsigned long long)c->width * c->height;
         P.tileCost = (unsigned int*)L.dTileCost.ptr;
@@ -726,9 +726,9 @@ int dispatchSplit(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t 
     const int k = overlap ? (c->lastLane = (c->lastLane + 1) % (frameCount <= 2u ? kLaunchLanes : 2)) : 0;
     c->counterSet = k;
     if (c->pipeline != 0) return dispatchImpl(c, frameFirst, frameCount, frameStride, counted, 0, false);
-    // The megakernel writes one 48-byte record per (sample, pixel) and a resolve pass folds them into
+    // The megakernel writes one 36-byte record per (sample, pixel) and a resolve pass folds them into
     // the images; a launch takes as many frames as the sample buffer's budget holds.
-    const uint64_t perFrame = (uint64_t)c->width * c->height * 48u;
+    const uint64_t perFrame = (uint64_t)c->width * c->height * kSampleBytes;
     uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint32_t>(frameCount, 65535u), c->sampleBudgetBytes / perFrame));
     uint32_t done = 0;
     while (done < frameCount) {
@@ -1280,7 +1280,7 @@ int pt_dispatch_static(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint
     const size_t pixels = (size_t)c->width * c->height;
     const size_t tiles = (size_t)((c->width + kMegaTile - 1) / kMegaTile) * (size_t)((c->height + kMegaTile - 1) / kMegaTile);
     const size_t costBytes = ((tiles + 1) * 4 + 255) / 256 * 256;  // per-tile cost words and the work counter
-    const size_t need = costBytes + (size_t)frameCount * pixels * 48u;
+    const size_t need = costBytes + (size_t)frameCount * pixels * kSampleBytes;
     if (need > kStaticScratchBytes)
         return fail(PT_ERR_INVALID, "pt_dispatch_static: " + std::to_string(frameCount) + " frames of " + std::to_string(c->width) + "x" +
                                         std::to_string(c->height) + " need " + std::to_string(need) + " bytes of scratch, the static array holds " +

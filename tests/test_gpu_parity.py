@@ -232,7 +232,7 @@ def test_launch_splitting_does_not_change_a_bit():
     p = R.default_params(96, 80)
     g.set_params(p)
     cpu = o.render(p, 96, 80, 3, 11, 2)  # FrameCount 3, 5, ..., 23
-    frame_bytes_mib = 1  # 96*80*48 B = 0.35 MiB per frame: a 1 MiB budget holds 2 frames per launch
+    frame_bytes_mib = 1  # 96*80*36 B = 0.26 MiB per frame: a 1 MiB budget holds 3 frames per launch
     for tuning in (dict(), dict(sample_budget_mib=frame_bytes_mib), dict(tile_split=16),
                    dict(sample_budget_mib=frame_bytes_mib, tile_split=0), dict(tile_order=0)):
         g.set_tuning(**dict(dict(sample_budget_mib=8192, tile_split=-1, tile_order=1), **tuning))

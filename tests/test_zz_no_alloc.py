@@ -71,7 +71,7 @@ def test_static_dispatch_limits_and_state():
         g.dispatch_static(1, 1, 1)
     assert e.value.code == -2
     g.dispatch(1, 1, 1)
-    frames_fit = (SCRATCH_BYTES - 4096) // (256 * 256 * 48)
+    frames_fit = (SCRATCH_BYTES - 4096) // (256 * 256 * 36)
     g.dispatch_static(2, frames_fit, 1)
     with pytest.raises(PtError) as e:
         g.dispatch_static(2, frames_fit + 1, 1)
