@@ -63,6 +63,14 @@ struct DeviceBuffer {
     }
 };
 
+// A buffer that lives as long as its scope (error returns included).
+struct ScopedBuffer : DeviceBuffer {
+    ScopedBuffer() = default;
+    ScopedBuffer(const ScopedBuffer&) = delete;
+    ScopedBuffer& operator=(const ScopedBuffer&) = delete;
+    ~ScopedBuffer() { release(); }
+};
+
 struct HostTexture {
     int width = 0, height = 0, channels = 0, format = 0;
     std::vector<unsigned char> bytes;
@@ -221,7 +229,7 @@ int collapseTree(pt_ctx* c, size_t nodeCount)
     }
     if ((nodeCount + 2) * sizeof(DevNode4) >= (1ull << 32))
         return fail(PT_ERR_SCENE, "node array of 4 GB or more (the kernels address records by 32-bit byte offsets)");
-    DeviceBuffer frontier[2], counters;
+    ScopedBuffer frontier[2], counters;
     HIP_TRY(frontier[0].ensure(nodeCount * sizeof(int2)));
     HIP_TRY(frontier[1].ensure(nodeCount * sizeof(int2)));
     HIP_TRY(counters.ensure(8));
@@ -1396,7 +1404,7 @@ int pt_debug_view(pt_ctx* c, int view)
     fillLaunchBlocks(c, 1, 1, 1, P, S);
     // the heat map walks the tree as the shader does, over the reference's node records: those of a device-built
     // tree are on the device already, uploaded ones are copied there for this call
-    DeviceBuffer uploaded;
+    ScopedBuffer uploaded;
     const RefNodeAlign* nodes = (const RefNodeAlign*)c->dRefNodes.ptr;
     if (view == PT_DEBUG_VIEW_BVH && !c->deviceGeometry) {
         HIP_TRY(uploaded.ensure(c->nodes.size() * sizeof(RefNodeAlign)));
@@ -1407,7 +1415,6 @@ int pt_debug_view(pt_ctx* c, int view)
     hipLaunchKernelGGL(debugViewKernel, grid, block, 0, c->stream, P, S, view, nodes, imagePtr(c, PT_IMAGE_RADIANCE));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));  // `uploaded` is freed with this scope
-    uploaded.release();
     return PT_OK;
 }
 
