@@ -826,7 +826,7 @@ void pt_destroy(pt_ctx* c)
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
     if (c->evFork) (void)hipEventDestroy(c->evFork);
-    DeviceBuffer* all[] = {&c->dWaveTimes, &c->dRefNodes, &c->dRefPrims, &c->dRgbStaging, &c->dNodes, &c->dTriangles, &c->dShading, &c->dMaterials, &c->dTextures, &c->dTexels,
+    DeviceBuffer* all[] = {&c->dWaveTimes, &c->dRefNodes, &c->dRefPrims, &c->dRgbStaging, &c->dNodes, &c->dNodes4, &c->dTriangles, &c->dShading, &c->dMaterials, &c->dTextures, &c->dTexels,
                            &c->dSrgbLut, &c->dEnvColorPdf, &c->dEnvSample, &c->dImages[0], &c->dImages[1],
                            &c->dImages[2]};
     for (DeviceBuffer* b : all) b->release();
