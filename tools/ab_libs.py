@@ -27,7 +27,7 @@ for r in range(4):
     g.clear(); g.dispatch(1, 64, 1); g.synchronize(); ms.append(g.last_dispatch_ms())
 st = g.stats(); rays = st.rays_closest + st.rays_any; waves = g.resident_waves()
 g.clear(); g.dispatch(1, 4, 1, counted=True); sc = g.stats(); r4 = sc.rays_closest + sc.rays_any
-print("%%-50s median %%8.3f ms  min %%8.3f  -> %%8.1f Mrays/s   %%.2f node visits + %%.2f triangle tests per ray, stack %%d, %%d waves resident" %% (os.path.basename(sys.argv[1]), np.median(ms), min(ms), rays / np.median(ms) / 1e3, sc.node_visits / r4, sc.triangle_tests / r4, sc.max_stack_depth, waves))
+print("%%-50s median %%8.3f ms  min %%8.3f  -> %%8.1f Mrays/s   %%.2f node visits + %%.2f triangle tests per ray, stack %%d, %%d waves resident, %%d wide levels" %% (os.path.basename(sys.argv[1]), np.median(ms), min(ms), rays / np.median(ms) / 1e3, sc.node_visits / r4, sc.triangle_tests / r4, sc.max_stack_depth, waves, g.tree_info()[0]))
 ''' % ROOT
 libs = sys.argv[1:]
 if libs[:1] == ["--bvh"]:
