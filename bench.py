@@ -402,7 +402,7 @@ def main():
             "roofline": {
                 # `achieved` / `frac` are ALGORITHMIC bytes over the trace kernel's HIP-event time against the HBM peak.
                 # What the counters say bounds the kernel is `bound` (from the committed PMC summary of this launch shape).
-                "bound": (pmc.get("bound") if pmc and pmc.get("bound") else ("hbm" if not cache_resident else "valu-issue")),
+                "bound": (pmc.get("bound") if pmc and pmc.get("bound") else ("hbm" if not cache_resident else "l1-gather")),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -411,11 +411,15 @@ def main():
                 "level": "L2 + Infinity Cache (scene cache resident)" if cache_resident else "HBM (scene exceeds the 256 MB Infinity Cache)",
                 "note": ("achieved / frac count ALGORITHMIC bytes against the HBM peak; on a cache-resident scene the L1 and L2 serve them "
                          "(frac can exceed 1): frac_l2 rates them against the L2s, traffic / fabric_gbps are the bytes measured leaving "
-                         "the L2s, valu_busy / lane_utilisation say what bounds the kernel"),
+                         "the L2s; l1_busy + l1_stall (share of the CUs' cycles in which the vector L1 takes an access, one per cycle, "
+                         "or is held up by misses in flight) and valu_pipe_share say what bounds the kernel"),
                 "frac_l2": achieved / L2_PEAK_GBS,
                 "fabric_gbps": (traffic / avg_kernel_s / 1e9) if traffic else None,
                 "fabric_frac": ((traffic / avg_kernel_s / 1e9) / (MALL_GATHER_GBS if cache_resident else HBM_PEAK_GBS)) if traffic else None,
                 "fabric_peak": MALL_GATHER_GBS if cache_resident else HBM_PEAK_GBS,
+                "l1_busy": pmc.get("l1_busy") if pmc else None,
+                "l1_stall": pmc.get("l1_stall") if pmc else None,
+                "valu_pipe_share": pmc.get("valu_pipe_share") if pmc else None,
                 "valu_busy": pmc.get("valu_busy") if pmc else None,
                 "lane_utilisation": pmc.get("lane_utilisation") if pmc else None,
                 "waves_per_simd": pmc.get("waves_per_simd") if pmc else None,

@@ -54,7 +54,8 @@ def test_pmc_summary_is_made_of_the_committed_counters_and_found_by_launch_shape
                     str(out)] + shape, check=True, cwd=ROOT, capture_output=True)
     t = json.loads(out.read_text())
     assert 0.5 < t["valu_busy"] <= 1.0 and 0.2 < t["lane_utilisation"] < 1.0 and 2.0 < t["waves_per_simd"] <= 3.0
-    assert t["bytes_per_launch"] == (2.0 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0 and t["bound"] == "valu-issue"
+    assert 0.5 < t["l1_busy"] < 1.0 and 0.9 < t["l1_busy"] + t["l1_stall"] < 1.1 and t["bound"] == "l1-gather"
+    assert t["bytes_per_launch"] == (2.0 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0 and t["bound"] == "l1-gather"
     committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
     assert {k: committed[k] for k in ("scene", "width", "height", "spp_per_step", "max_bounces", "subdivide", "bvh", "copies")} == \
         {k: t[k] for k in ("scene", "width", "height", "spp_per_step", "max_bounces", "subdivide", "bvh", "copies")}

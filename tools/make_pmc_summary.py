@@ -34,10 +34,19 @@ def main(src, dst, shape):
         "write_size_kb": write,
         "correction": ("gfx950: FETCH_SIZE tallies 128-B fabric requests as 64 B, so it is doubled; WRITE_SIZE is taken as reported; "
                        "both are in KB.  The counters sit on the L2's fabric side: Infinity-Cache hits are included."),
-        # share of the launch's cycles in which a SIMD's VALU was executing (4 cycles per wave instruction)
-        # (at most 1: a wave instruction whose active lanes all sit in one half of the wave issues in two cycles, so a
-        # divergent kernel can retire more than one instruction per four cycles -- valu_cycles_per_inst says how many)
+        # SQ_ACTIVE_INST_VALU counts, in units of four cycles, the time waves spend with a vector instruction in issue;
+        # against the SIMDs' cycles it says how many waves per SIMD do so on average (capped at 1).  The pipe itself
+        # retires a wave instruction in about 2.4 cycles once two or more waves feed it (tools/ubench/halfwave.hip), so
+        # valu_pipe_share = 2.4 / valu_cycles_per_inst is the share of the pipe's throughput in use.
         "valu_busy": min(1.0, 4.0 * c["SQ_ACTIVE_INST_VALU"] / (busy * SIMDS)) if "SQ_ACTIVE_INST_VALU" in c else None,
+        "valu_pipe_share": min(1.0, 2.4 * c["SQ_INSTS_VALU"] / (busy * SIMDS)),
+        # The vector L1 (TCP) takes one access per cycle and CU (an access is 8 bytes of a lane's scattered read, 16 of a
+        # whole line read by eight lanes, up to 64 of adjacent 4- and 8-byte reads: tools/ubench/l1rate.hip under the
+        # same counter); l1_busy is the share of the CUs' cycles with an access, l1_stall the share it spent held up
+        # by misses in flight.
+        "l1_busy": c["TCP_TOTAL_CACHE_ACCESSES_sum"] / (busy * 256.0) if "TCP_TOTAL_CACHE_ACCESSES_sum" in c else None,
+        "l1_stall": c["TCP_PENDING_STALL_CYCLES_sum"] / (busy * 256.0) if "TCP_PENDING_STALL_CYCLES_sum" in c else None,
+        "l1_accesses": c.get("TCP_TOTAL_CACHE_ACCESSES_sum"),
         "valu_cycles_per_inst": busy * SIMDS / c["SQ_INSTS_VALU"],
         "lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (WAVE * c["SQ_INSTS_VALU"]),
         # SQ_WAVE_CYCLES counts resident waves in units of four cycles
@@ -48,7 +57,9 @@ def main(src, dst, shape):
         "launch_info": k.get("launch_info"),
     })
     vb = out["valu_busy"] or 0.0
-    out["bound"] = "valu-issue" if vb >= 0.6 else ("hbm" if traffic / (k["avg_ns"] / 1e9) / 1e9 > 4000.0 else "latency")
+    l1 = (out["l1_busy"] or 0.0) + (out["l1_stall"] or 0.0)
+    out["bound"] = ("l1-gather" if l1 >= 0.9 and (out["l1_busy"] or 0.0) >= 0.5 else
+                    "valu-issue" if vb >= 0.6 else ("hbm" if traffic / (k["avg_ns"] / 1e9) / 1e9 > 4000.0 else "latency"))
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
 

@@ -62,6 +62,10 @@ int main()
     for (int w : {1, 3}) {
         run<4, 8>("16 B per lane, 8 lanes per line (contiguous)", buf, out, ~0ull, w);
         run<4, 1>("16 B per lane, a line per lane", buf, out, ~0ull, w);
+        run<4, 2>("16 B per lane, 2 lanes per line (32 B contiguous)", buf, out, ~0ull, w);
+        run<4, 4>("16 B per lane, 4 lanes per line (64 B contiguous)", buf, out, ~0ull, w);
+        run<2, 2>("8 B per lane, 2 lanes per line (16 B contiguous)", buf, out, ~0ull, w);
+        run<2, 4>("8 B per lane, 4 lanes per line (32 B contiguous)", buf, out, ~0ull, w);
         run<4, 1>("16 B per lane, a line per lane, 43 lanes", buf, out, (1ull << 43) - 1, w);
         run<4, 1>("16 B per lane, a line per lane, 22 lanes", buf, out, (1ull << 22) - 1, w);
         run<4, 1>("16 B per lane, a line per lane, 22 scattered", buf, out, 0x9249249249249249ull, w);
