@@ -216,18 +216,17 @@ def self_launch(args, argv):
 def pmc_summary(args, W, H, S):
     """Counter-derived figures of the trace kernel from the committed rocprofv3 PMC summary, valid
     only for the launch shape they were collected on."""
-    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
-    if not os.path.exists(path):
-        return None
-    try:
-        t = json.load(open(path))
-    except Exception:
-        return None
-    shape = (t.get("scene"), t.get("width"), t.get("height"), t.get("spp_per_step"), t.get("max_bounces"), t.get("subdivide"),
-             t.get("bvh"), t.get("copies"))
-    if shape != (args.scene, W, H, S, args.bounces, args.subdivide, args.bvh, args.copies):
-        return None
-    return t
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json"))):
+        try:
+            t = json.load(open(path))
+        except Exception:
+            continue
+        shape = (t.get("scene"), t.get("width"), t.get("height"), t.get("spp_per_step"), t.get("max_bounces"), t.get("subdivide"),
+                 t.get("bvh"), t.get("copies"))
+        if shape == (args.scene, W, H, S, args.bounces, args.subdivide, args.bvh, args.copies):
+            return t
+    return None
 
 
 def main():
