@@ -314,6 +314,8 @@ def main():
     for w in range(args.warmup):
         sr.render_step(w, S)
         sr.reduce()
+    if distributed and args.warmup == 0:
+        sr.reduce()  # untimed: the first collective of a communicator sets its channels up
     sync()
     if distributed:
         dist.barrier()
