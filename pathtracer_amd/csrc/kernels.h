@@ -47,10 +47,11 @@
 namespace ptcore {
 
 constexpr int kBlockThreads = 256;
-// Waves per SIMD the megakernel is compiled for.  Measured on the benchmark scene (cache resident,
-// VALU bound): 4 waves (128 VGPRs, ~105 spilled values, all outside the traversal loop) and 3 waves
-// (168 VGPRs, 25 spills) within 0.5 % of each other, 2 waves 35 % slower, 5 waves (96 VGPRs, ~185
-// spills) 80 % slower.  Scenes that miss the caches want the occupancy: 4.
+// Waves per SIMD of a megakernel instantiation that does not say (the host's table names it for every variant it
+// launches: 3, i.e. 168 VGPRs and next to nothing spilled; the 4-wave build, 128 VGPRs and some 55 values spilled
+// in the shading blocks, is 14 % slower on the four-wide kernel, 2 waves 35 %, 5 waves 80 %).  What bounds the
+// kernel is the vector L1's access rate (one access per cycle and CU, two for a lane's 16-byte read), which more
+// resident waves do not raise.
 #ifndef PT_WAVES_PER_SIMD
 #define PT_WAVES_PER_SIMD 4
 #endif
