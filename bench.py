@@ -200,7 +200,7 @@ def self_launch(args, argv):
     """`--gpus N` outside a torchrun environment: start N ranks (one process per GPU) as a child
     torch.distributed.run, which must happen before this process touches the GPU, and pass its exit
     code on; rank 0 of the child prints the line."""
-    if not args.stub:
+    if not args.stub and os.environ.get("PT_BENCH_BACKEND", "nccl") == "nccl":
         have = torch.cuda.device_count()  # counting devices does not initialise the GPU
         if have < args.gpus:
             print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible", file=sys.stderr)
@@ -270,11 +270,17 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     distributed = world > 1
+    # PT_BENCH_BACKEND=gloo: a rehearsal of the N > 1 path on fewer GPUs than ranks (RCCL takes one rank per GPU):
+    # ranks share the devices and the collectives go through gloo.  Not a measurement.
+    backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
+    device_index = local_rank
     if not args.stub:
-        torch.cuda.set_device(local_rank)
+        if backend != "nccl":
+            device_index = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(device_index)
     if distributed:
         import torch.distributed as dist
-        if args.stub:
+        if args.stub or backend != "nccl":
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -290,7 +296,7 @@ def main():
     else:
         from pathtracer_amd.distributed import ShardedRenderer
         work = build_workload(args)
-        sr = ShardedRenderer(W, H, local_rank, rank, world)
+        sr = ShardedRenderer(W, H, device_index, rank, world)
         g = sr.renderer
         if args.tuning:  # before the scene goes in: some settings steer the device BVH builder
             g.set_tuning(**{k: int(v) for k, v in (item.split("=") for item in args.tuning.split(","))})
@@ -397,6 +403,7 @@ def main():
                 "scene": args.scene, "width": W, "height": H, "max_bounces": args.bounces, "spp_per_step_per_gpu": S,
                 "total_spp": total_spp, "parallelism": f"sample-sharded x{world}" if world > 1 else "single GPU",
                 "reduce": ("none (one GPU)" if world == 1 else
+                           "REHEARSAL over gloo with ranks sharing GPUs: not a measurement" if backend != "nccl" and not args.stub else
                            "one RCCL all-reduce per step" if args.reduce_every_step else "one RCCL all-reduce per render (after the last step, timed)"),
                 "bvh_build_seconds": round(work["bvh_seconds"], 3),
             },

@@ -55,3 +55,19 @@ def test_bench_two_gpus_self_launch():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["value"] > 0
+
+
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """bench.py's N > 1 control flow (self-launch, sharding by FrameCount, sum mode, the reduce inside the timed
+    region, max-over-ranks timing) on however many GPUs there are: with PT_BENCH_BACKEND=gloo the ranks share
+    the devices (RCCL takes one rank per GPU).  A rehearsal, not a measurement."""
+    import json
+    env = _env()
+    env["PT_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--spp-per-step", "8", "--width", "640", "--height", "360", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["total_spp"] == 2 * 8 * 2
+    assert "REHEARSAL" in out["config"]["reduce"]
