@@ -270,6 +270,12 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     distributed = world > 1
+    # every rank builds the same tree on the host before the timed region: give each its share of the cores
+    # (OMP_NUM_THREADS is the job's CPU share where the launcher sets it; os.cpu_count() is the whole machine)
+    omp = os.environ.get("OMP_NUM_THREADS", "")
+    cores = int(omp) if omp.isdigit() and int(omp) > 0 else (os.cpu_count() or 1)
+    host_threads = max(1, min(16, cores // world))
+    os.environ.setdefault("PT_HOST_THREADS", str(host_threads))
     # PT_BENCH_BACKEND=gloo: a rehearsal of the N > 1 path on fewer GPUs than ranks (RCCL takes one rank per GPU):
     # ranks share the devices and the collectives go through gloo.  Not a measurement.
     backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
@@ -278,12 +284,24 @@ def main():
         if backend != "nccl":
             device_index = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(device_index)
+    over_gloo = args.stub or backend != "nccl"
     if distributed:
+        import datetime
+        import faulthandler
         import torch.distributed as dist
-        if args.stub or backend != "nccl":
-            dist.init_process_group("gloo")
+        # A rank that blocks (rendezvous, a collective whose peer died) must end with a traceback, not sit
+        # silently until somebody's outer limit: PT_BENCH_WATCHDOG_S seconds after start every rank dumps its
+        # threads' stacks to stderr and exits (0 = off; the default leaves a real N-GPU run ample time).
+        watchdog = float(os.environ.get("PT_BENCH_WATCHDOG_S", "120" if over_gloo else "1500"))
+        if watchdog > 0:
+            faulthandler.dump_traceback_later(watchdog, exit=True)
+        if over_gloo:
+            # gloo picks its interface from the host name unless told otherwise; MASTER_ADDR only places the store
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=60))
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=600))
 
     def sync():
         if not args.stub:
@@ -328,8 +346,10 @@ def main():
     sync()
     rays = 0
     kernel_ms = []
+    step_ms = []  # this rank's wall time per step (each ends in the counter read, which synchronises)
     t0 = time.perf_counter()
     for k in range(args.steps):
+        t_step = time.perf_counter()
         sr.render_step(k, S)
         if args.reduce_every_step:
             sr.reduce()
@@ -341,6 +361,7 @@ def main():
             kernel_ms.append(g.last_kernel_ms())
         except Exception:  # the wavefront pipeline (--tuning pipeline=1) has no single trace kernel: whole dispatch
             kernel_ms.append((g.last_dispatch_ms(), 0.0))
+        step_ms.append((time.perf_counter() - t_step) * 1e3)
     if not args.reduce_every_step:
         sr.reduce()  # one collective per render (the K steps)
     sync()
@@ -349,12 +370,15 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
 
+    rank_ms = [elapsed * 1e3]
     if distributed:
-        dev = "cpu" if args.stub else "cuda"
+        dev = "cpu" if over_gloo else "cuda"  # scalars: host tensors under gloo, device tensors under RCCL
         t = torch.tensor([elapsed, float(rays)], device=dev, dtype=torch.float64)
-        tmax = t.clone()
+        tmax, tmin = t.clone(), t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        rank_ms = [float(tmin[0]) * 1e3, float(tmax[0]) * 1e3]
         elapsed, rays = float(tmax[0]), float(t[1])
 
     if rank == 0:
@@ -388,6 +412,11 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_median": float(np.median(step_ms)),
+            "ms_per_step_min": float(np.min(step_ms)),
+            "ms_per_step_max": float(np.max(step_ms)),
+            "rank_ms_min": rank_ms[0],
+            "rank_ms_max": rank_ms[-1],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -408,19 +437,25 @@ def main():
                 "bvh_build_seconds": round(work["bvh_seconds"], 3),
             },
             "roofline": {
-                # `achieved` / `frac` are ALGORITHMIC bytes over the trace kernel's HIP-event time against the HBM peak.
-                # What the counters say bounds the kernel is `bound` (from the committed PMC summary of this launch shape).
+                # `achieved` = ALGORITHMIC bytes per launch over the trace kernel's HIP-event time, measured in this run.
+                # `peak` / `frac` rate them against the memory level that serves them: the eight L2s for a scene the
+                # caches hold, HBM for one they cannot; `frac_hbm` is the same figure against the HBM peak.
                 "bound": (pmc.get("bound") if pmc and pmc.get("bound") else ("hbm" if not cache_resident else "l1-gather")),
                 "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
+                "peak": L2_PEAK_GBS if cache_resident else HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
+                "frac": achieved / (L2_PEAK_GBS if cache_resident else HBM_PEAK_GBS),
+                "frac_hbm": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "level": "L2 + Infinity Cache (scene cache resident)" if cache_resident else "HBM (scene exceeds the 256 MB Infinity Cache)",
-                "note": ("achieved / frac count ALGORITHMIC bytes against the HBM peak; on a cache-resident scene the L1 and L2 serve them "
-                         "(frac can exceed 1): frac_l2 rates them against the L2s, traffic / fabric_gbps are the bytes measured leaving "
-                         "the L2s; l1_busy + l1_stall (share of the CUs' cycles in which the vector L1 takes an access, one per cycle, "
-                         "or is held up by misses in flight) and valu_pipe_share say what bounds the kernel"),
+                "level": ("L2 (aggregate of the eight per-XCD L2s; the scene is cache resident)" if cache_resident
+                          else "HBM (scene exceeds the 256 MB Infinity Cache)"),
+                "note": ("measured in this run: achieved, frac, frac_hbm, kernel_ms_avg, the per-ray counts, resolve_kernel, ms_per_step_*. "
+                         "Read from pmc_source (rocprofv3 counter passes of the same command on the same launch shape, not this run): "
+                         "traffic, fabric_gbps, fabric_frac, l1_busy, l1_stall, valu_pipe_share, valu_busy, lane_utilisation, "
+                         "waves_per_simd, l2_hit, bound. achieved counts ALGORITHMIC bytes: on a cache-resident scene the vector L1s "
+                         "and the L2s serve them, so frac_hbm can exceed 1 and peak is the L2s' measured aggregate; traffic / "
+                         "fabric_gbps are the bytes leaving the L2s; l1_busy + l1_stall (share of the CUs' cycles in which the vector "
+                         "L1 takes an access, one per cycle, or is held up by misses in flight) say what bounds the kernel"),
                 "frac_l2": achieved / L2_PEAK_GBS,
                 "fabric_gbps": (traffic / avg_kernel_s / 1e9) if traffic else None,
                 "fabric_frac": ((traffic / avg_kernel_s / 1e9) / (MALL_GATHER_GBS if cache_resident else HBM_PEAK_GBS)) if traffic else None,
@@ -428,7 +463,7 @@ def main():
                 "l1_busy": pmc.get("l1_busy") if pmc else None,
                 "l1_stall": pmc.get("l1_stall") if pmc else None,
                 "valu_pipe_share": pmc.get("valu_pipe_share") if pmc else None,
-                "valu_busy": pmc.get("valu_busy") if pmc else None,
+                "valu_busy": (pmc.get("valu_busy_raw", pmc.get("valu_busy"))) if pmc else None,
                 "lane_utilisation": pmc.get("lane_utilisation") if pmc else None,
                 "waves_per_simd": pmc.get("waves_per_simd") if pmc else None,
                 "l2_hit": pmc.get("l2_hit") if pmc else None,

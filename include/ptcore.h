@@ -288,9 +288,14 @@ int pt_dispatch_counted(pt_ctx* ctx, uint32_t frame_first, uint32_t frame_count,
  * plan).  PT_ERR_INVALID when 256 + 36 bytes x width x height x frame_count (+ 4 per 8x8 tile) exceed the
  * array: dispatch fewer frames per call.  PT_ERR_STATE when scene buffers or textures changed since the
  * last pt_dispatch (which uploads them), or under the wavefront scheduler.  All contexts on one GPU share
- * the array: calls that overlap on one GPU (different streams or threads) race. */
+ * the array: calls that overlap on one GPU (different streams or threads) race.
+ * The kernel's occupancy is asked of the runtime when the context is created, so a call itself makes no
+ * runtime query either. */
 #define PT_STATIC_SCRATCH_BYTES (128u << 20)
 int pt_dispatch_static(pt_ctx* ctx, uint32_t frame_first, uint32_t frame_count, uint32_t frame_stride);
+/* No counterpart in the reference.  The limits of pt_dispatch_static as built: size of the static array
+ * and bytes of one sample record (either pointer may be null). */
+int pt_static_scratch_info(uint64_t* scratch_bytes, uint32_t* sample_record_bytes);
 /* Multiply the three images by `scale` (sum mode: 1/N after the cross-GPU reduce). */
 int pt_scale_images(pt_ctx* ctx, float scale);
 int pt_synchronize(pt_ctx* ctx);
@@ -339,15 +344,16 @@ int pt_last_kernel_ms(pt_ctx* ctx, float* trace_ms_out, float* resolve_ms_out);
 int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, uint64_t* shading_bytes);
 
 /* Tuning hook, not part of the drop-in surface (no counterpart in the reference).  key 0: scheduler
- * (0 = single-launch megakernel, the default; 1 = wavefront pipeline); 1: megakernel traversal-phase
+ * (0 = single-launch megakernel, the default; 1 = wavefront pipeline, which takes trees of at most 21
+ * four-wide levels where the megakernel takes 32: select it before the upload so that the fold aims for that); 1: megakernel traversal-phase
  * exit threshold in 64ths of the lanes that entered the phase (default 32); 2: wavefront refill threshold in idle
  * lanes (default 16); 3: wavefront iterations between read-backs of the live-ray count (default 2);
  * 4: traverse grid size in blocks (0 = sized from the occupancy query); 5: megakernel hit-shading
  * threshold in 64ths of the live lanes (default 16): hits wait until that share of the wave holds one;
  * 6: costliest-block-first launch order from the previous launch's per-tile cost (default 1); 7: tile
  * split: a tile whose cost exceeds 1/value of the launch's lower bound (total cost / resident waves) has
- * its samples spread over several blocks; 0 = one block per tile; -1 (default) = 2 for images with no
- * more tiles than resident waves, else 1;
+ * its samples spread over several work items; 0 = one item per tile; -1 (default) = 8 for images with
+ * fewer tiles than resident waves, else 32;
  * 8: budget of the megakernel's sample buffer in MiB (36 bytes per sample and pixel; a dispatch is cut
  * into launches that fit; default 8192); 9: megakernel run by a grid of resident waves that pull the work
  * items off a counter (1, the default) or by one block per work item (0); 10: device

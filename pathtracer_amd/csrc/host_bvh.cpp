@@ -22,6 +22,7 @@
 #include <atomic>
 #include <cstring>
 #include <future>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
@@ -249,7 +250,9 @@ size_t BuildBvhWithSah(RefPrimitive* prims, size_t count, int leafSize, std::vec
         keys[i].id = (uint32_t)i;
     }
     if (threads <= 0) {
-        threads = (int)std::thread::hardware_concurrency();
+        // PT_HOST_THREADS: a caller that runs several processes on one host (one per GPU) gives each its share
+        const char* env = std::getenv("PT_HOST_THREADS");
+        threads = env ? std::atoi(env) : (int)std::thread::hardware_concurrency();
         if (threads > 16) threads = 16;
         if (threads < 1) threads = 1;
     }

@@ -216,7 +216,7 @@ int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count);
 // and drops the binary one.  A query's stack holds at most three entries per level of the wide tree.
 constexpr int kStackLds = 48;      // megakernel: entries in LDS (40 ... 48 measured alike: twelve waves per CU fit either way) ...
 constexpr int kStackPrivate = 48;  // ... and, for deeper trees, in lane-private memory
-constexpr int kStackWavefront = 63;  // wavefront pipeline: all in LDS (64 rows of 256 lanes = the 64 KB a block may have)
+constexpr int kStackWavefront = 63;  // wavefront pipeline: all in LDS (64 rows of 256 lanes = 64 KB, next to 2 KB of its other tables)
 int collapseTree(pt_ctx* c, size_t nodeCount)
 {
     c->wideLevels = 0;
@@ -258,7 +258,9 @@ int collapseTree(pt_ctx* c, size_t nodeCount)
         c->wideLevels = levels;
         c->foldedLevelByLevel = uniform != 0;
         wideCount = h[0];
-        if (3 * levels <= kStackLds + kStackPrivate) break;
+        // (with the wavefront pipeline selected at upload time its shorter stack decides; selected later, a tree folded
+        // to between 22 and 32 levels is refused by its dispatch)
+        if (3 * levels <= (c->pipeline == 1 ? kStackWavefront : kStackLds + kStackPrivate)) break;
     }
     if (3 * c->wideLevels > kStackLds + kStackPrivate)
         return fail(PT_ERR_SCENE, "BVH too deep: " + std::to_string(c->wideLevels) + " levels of four-wide nodes, the traversal stack holds " +
@@ -621,7 +623,9 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
         // faster than a half at 512 x 512 and 3 % at 720p, makes no difference at 1080p, and is 4 % slower than an
         // eighth at 256 x 256, where there are fewer tiles than waves.  Unless set by hand.
         const unsigned split = c->tileSplit >= 0 ? (unsigned)c->tileSplit : (tiles < slots ? 8u : 32u);
-        const size_t capacity = tiles + (size_t)split * c->computeUnits * 16u;  // (sized for the most waves any variant keeps)
+        // planPartsKernel adds fewer than max(1, split) * slots items to the one per tile: the list holds them all, whatever
+        // number of resident waves the runtime reports for the variant in use
+        const size_t capacity = tiles + (size_t)std::max(1u, split) * slots;
         if (L.tileCostTiles != tiles || L.blockCapacity != capacity) {
             for (DeviceBuffer* b : {&L.dTileCost, &L.dTileParts, &L.dTileKey, &L.dTileKeySorted, &L.dTileIds, &L.dTileOrder,
                                     &L.dPartsInOrder, &L.dBlockStart})
@@ -807,6 +811,15 @@ int pt_create(int device, int width, int height, pt_ctx** out)
         HIP_TRY(hipEventCreateWithFlags(&L.evFree, hipEventDisableTiming));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    // pt_dispatch_static must not query the runtime (its callers may be under graph capture): the occupancy of the
+    // variants it can launch is taken here
+    for (int deep = 0; deep < 2; deep++) {
+        c->wideLevels = deep ? kStackLds : 1;
+        uint32_t waves = 0;
+        int rcw = residentWaves(c.get(), traceVariant(c.get(), false, true), waves);
+        if (rcw != PT_OK) return rcw;
+    }
+    c->wideLevels = 0;
     *out = c.release();
     return PT_OK;
 }
@@ -1310,13 +1323,20 @@ int pt_dispatch_static(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint
     HIP_TRY(hipMemsetAsync(base, 0, costBytes, c->stream));  // the array keeps the previous call's contents
     const TraceKernel kernel = traceVariant(c, false, true);
     uint32_t slots = 0;
-    const int rcs = residentWaves(c, kernel, slots);  // (asks the runtime about the kernel on first use; allocates nothing on the device)
+    const int rcs = residentWaves(c, kernel, slots);  // (known since pt_create unless four waves per SIMD were asked for)
     if (rcs != PT_OK) return rcs;
     hipLaunchKernelGGL(kernel, dim3((unsigned)std::min<size_t>(tiles, slots)), dim3(kMegaThreads), 0, c->stream, P, S, img, ctr);
     hipLaunchKernelGGL(resolveKernel, dim3((unsigned)((P.pixels + 255) / 256)), dim3(256), 0, c->stream, P, img);
     HIP_TRY(hipGetLastError());
     c->timed = false;  // no events around this launch
     c->kernelTimed = false;
+    return PT_OK;
+}
+
+int pt_static_scratch_info(uint64_t* scratchBytes, uint32_t* sampleRecordBytes)
+{
+    if (scratchBytes) *scratchBytes = kStaticScratchBytes;
+    if (sampleRecordBytes) *sampleRecordBytes = (uint32_t)kSampleBytes;
     return PT_OK;
 }
 
@@ -1470,8 +1490,8 @@ int pt_scene_bytes(pt_ctx* c, uint64_t* nodeBytes, uint64_t* triangleBytes, uint
 // threshold in 64ths of the live lanes; 2: wavefront refill threshold (idle lanes); 3: wavefront
 // iterations between read-backs of the live-ray count; 4: traverse grid size in blocks (0 = auto);
 // 5: megakernel hit-shading threshold in 64ths of the live lanes; 6: launch plan from the previous launch's tile costs on/off;
-// 7: tile split: no megakernel block may cost more than 1/value of the launch's lower bound (0: one block per tile,
-// -1: chosen from the number of tiles per wave slot); 8: sample-buffer budget in MiB (a dispatch is
+// 7: tile split: no work item of the megakernel may cost more than 1/value of the launch's lower bound (0: one item per
+// tile, -1: 8 for images with fewer tiles than resident waves, else 32); 8: sample-buffer budget in MiB (a dispatch is
 // cut into launches whose sample records fit); 9: megakernel run by resident waves that pull the
 // work items off a counter (1, the default) or by one block per item (0); 10: device BVH
 // builder: clustering search radius (0 = Morton radix tree); 11: megakernel compiled for 3 or 4 waves per SIMD

@@ -22,10 +22,18 @@ def shard_frames(rank, world, total_spp, first_frame=1):
 
 
 def reduce_sum(images, group=None):
-    """In-place sum over ranks of a stacked accumulation tensor (the path's only collective)."""
+    """In-place sum over ranks of a stacked accumulation tensor (the path's only collective).  Device
+    tensors go to RCCL as they are; under a gloo group (CPU rehearsals of the N > 1 path, ranks that
+    share a GPU) a device tensor is staged through host memory, so that gloo only ever sees host
+    tensors."""
     import torch.distributed as dist
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(images, op=dist.ReduceOp.SUM, group=group)
+        if images.is_cuda and dist.get_backend(group) == "gloo":
+            host = images.cpu()  # synchronises the current stream
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            images.copy_(host)
+        else:
+            dist.all_reduce(images, op=dist.ReduceOp.SUM, group=group)
     return images
 
 

@@ -120,6 +120,7 @@ SYMBOLS = {
     "pt_dispatch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
     "pt_dispatch_counted": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
     "pt_dispatch_static": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
+    "pt_static_scratch_info": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]),
     "pt_scale_images": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float]),
     "pt_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
     "pt_read_image": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),

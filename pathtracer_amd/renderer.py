@@ -271,6 +271,13 @@ def set_camera(params, eye, center, width, height, fovy=1.57, up=(0.0, 1.0, 0.0)
     return params
 
 
+def static_scratch_info():
+    """(bytes of pt_dispatch_static's static device array, bytes of one sample record) of the library as built."""
+    size, rec = ctypes.c_uint64(), ctypes.c_uint32()
+    check(_l.load().pt_static_scratch_info(ctypes.byref(size), ctypes.byref(rec)))
+    return size.value, rec.value
+
+
 def build_bvh_sah(prims100, leaf_size=4, full_sweep=False):
     """prims100: (n, 25) float32 view of 100-B records. Returns (reordered prims, nodes (m, 10)).
     full_sweep: without the reference's cost cap (a different, better tree)."""

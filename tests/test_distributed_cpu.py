@@ -34,7 +34,11 @@ def _free_port():
 def _worker(rank, world, port, spp, width, height, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # both ranks are on this host; do not resolve the host name
+    import datetime
+    import faulthandler
+    faulthandler.dump_traceback_later(150, exit=True)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
     from oracle import binding as ob
     from pathtracer_amd import renderer as R
     from tests.common import built_scene, environment

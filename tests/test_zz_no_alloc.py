@@ -10,7 +10,12 @@ from tests.common import built_scene, environment
 
 pytestmark = pytest.mark.gpu
 
-SCRATCH_BYTES = 128 << 20  # PT_STATIC_SCRATCH_BYTES
+
+
+def _free_device_memory():
+    import torch
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info(0)[0]  # hipMemGetInfo: free bytes on the device
 
 
 def _context(width, height, recipe, bounces):
@@ -42,6 +47,13 @@ def test_static_dispatch_matches_dispatch_twice_second_smaller():
     big.dispatch(1, 5, 1)  # also uploads the scene; the static entry point uploads nothing
     want_big = _images(big)
     big.clear()
+    big.synchronize()
+    free_before = _free_device_memory()
+    big.dispatch_static(1, 5, 1)
+    big.dispatch_static(6, 1, 1)
+    big.synchronize()
+    assert _free_device_memory() == free_before  # the entry point's defining property: nothing was allocated
+    big.clear()
     big.dispatch_static(1, 5, 1)
     got_big = _images(big)
     assert _same_bits(got_big, want_big)
@@ -71,7 +83,9 @@ def test_static_dispatch_limits_and_state():
         g.dispatch_static(1, 1, 1)
     assert e.value.code == -2
     g.dispatch(1, 1, 1)
-    frames_fit = (SCRATCH_BYTES - 4096) // (256 * 256 * 36)
+    scratch_bytes, record_bytes = R.static_scratch_info()
+    assert scratch_bytes >= (64 << 20) and record_bytes == 36
+    frames_fit = (scratch_bytes - 4096) // (256 * 256 * record_bytes)
     g.dispatch_static(2, frames_fit, 1)
     with pytest.raises(PtError) as e:
         g.dispatch_static(2, frames_fit + 1, 1)

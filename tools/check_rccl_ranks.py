@@ -4,9 +4,11 @@ every rank renders its FrameCount shard through ShardedRenderer (sum mode, kerne
 torch-owned accumulation tensor, snapshot + RCCL all-reduce on a second stream), and rank 0 checks
 reduce() + resolve() against a plain single-GPU running mean of all the frames.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 tools/check_rccl_ranks.py"""
+import faulthandler
 import os
 import sys
 
+faulthandler.dump_traceback_later(240, exit=True)  # a blocked rank ends with its stacks on stderr
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -18,7 +20,8 @@ from tests.common import built_scene, environment  # noqa: E402
 
 rank, local, world = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(local)
-dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+import datetime  # noqa: E402
+dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=180))
 nodes, prims, mats = built_scene("TorusMixed")
 hdri, cache = environment(256, 128)
 w, h, spp_per_rank, steps = 256, 192, 3, 2

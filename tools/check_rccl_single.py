@@ -2,9 +2,11 @@
 """One-GPU rehearsal of the multi-GPU data path: a 1-rank RCCL group, the kernel writing into the
 torch-owned accumulation tensor on the shared stream, and the sum all-reduce issued on that tensor.
 (With one rank the all-reduce is an identity; the point is that every call of the N > 1 path runs.)"""
+import faulthandler
 import os
 import sys
 
+faulthandler.dump_traceback_later(120, exit=True)  # a blocked rank ends with its stacks on stderr
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29533")  # tests pass a free port
@@ -17,7 +19,8 @@ from pathtracer_amd.distributed import ShardedRenderer  # noqa: E402
 from tests.common import built_scene, environment  # noqa: E402
 
 torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+import datetime  # noqa: E402
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0), timeout=datetime.timedelta(seconds=90))
 nodes, prims, mats = built_scene("TorusMixed")
 hdri, cache = environment(256, 128)
 w, h, spp = 256, 192, 8

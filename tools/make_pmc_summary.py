@@ -39,6 +39,7 @@ def main(src, dst, shape):
         # retires a wave instruction in about 2.4 cycles once two or more waves feed it (tools/ubench/halfwave.hip), so
         # valu_pipe_share = 2.4 / valu_cycles_per_inst is the share of the pipe's throughput in use.
         "valu_busy": min(1.0, 4.0 * c["SQ_ACTIVE_INST_VALU"] / (busy * SIMDS)) if "SQ_ACTIVE_INST_VALU" in c else None,
+        "valu_busy_raw": 4.0 * c["SQ_ACTIVE_INST_VALU"] / (busy * SIMDS) if "SQ_ACTIVE_INST_VALU" in c else None,
         "valu_pipe_share": min(1.0, 2.4 * c["SQ_INSTS_VALU"] / (busy * SIMDS)),
         # The vector L1 (TCP) takes one access per cycle and CU (an access is 8 bytes of a lane's scattered read, 16 of a
         # whole line read by eight lanes, up to 64 of adjacent 4- and 8-byte reads: tools/ubench/l1rate.hip under the
