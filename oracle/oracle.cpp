@@ -41,6 +41,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -299,7 +300,14 @@ static vec4 bilinear(const Scene& s, const Texture& t, vec2 uv)
     return r;
 }
 // Library/common.glsl:167-175 -- the 64-bit handle is a 1-based texture slot here.
-static vec4 SampleBindlessTexture(const Ctx& c, uint64_t handle, vec2 uv) { return bilinear(*c.s, c.s->textures[(size_t)handle], uv); }
+static vec4 SampleBindlessTexture(const Ctx& c, uint64_t handle, vec2 uv)
+{
+    if (handle >= c.s->textures.size() || c.s->textures[(size_t)handle].w <= 0) {  // a test's mistake: say so instead of reading past the table
+        std::fprintf(stderr, "oracle: material refers to texture slot %llu, which was never set\n", (unsigned long long)handle);
+        std::abort();
+    }
+    return bilinear(*c.s, c.s->textures[(size_t)handle], uv);
+}
 static vec3 envTexel(const std::vector<float>& img, int w, int x, int y)
 {
     const float* p = &img[3 * ((size_t)y * w + x)];

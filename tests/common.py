@@ -92,3 +92,28 @@ def sah_cost(nodes48):
     leaf = used & (n > 0)
     inner = used & (n == 0)
     return (area[inner].sum() * 1.0 + (area[leaf] * n[leaf]).sum() * 1.0) / area[1]
+
+
+def image_hash(array):
+    """A checksum of checksums of an array's bytes, in numpy alone (so that it needs neither library):
+    FNV-1a-64 of every row (the first axis; a 1-D array is cut into rows of 4096 bytes, the last one
+    short), all rows side by side, then FNV-1a-64 of the rows' hashes as little-endian bytes."""
+    a = np.ascontiguousarray(array)
+    raw = a.view(np.uint8).reshape(a.shape[0], -1) if a.ndim > 1 else a.view(np.uint8).ravel()
+    offset, prime = np.uint64(1469598103934665603), np.uint64(1099511628211)
+
+    def rows_fnv(rows):  # rows: (n, m) uint8 -> (n,) uint64
+        h = np.full(rows.shape[0], offset, np.uint64)
+        with np.errstate(over="ignore"):
+            for k in range(rows.shape[1]):
+                h = (h ^ rows[:, k].astype(np.uint64)) * prime
+        return h
+
+    if raw.ndim == 1:
+        full = raw.size // 4096 * 4096
+        hashes = rows_fnv(raw[:full].reshape(-1, 4096)) if full else np.zeros(0, np.uint64)
+        if raw.size > full:
+            hashes = np.concatenate([hashes, rows_fnv(raw[full:].reshape(1, -1))])
+    else:
+        hashes = rows_fnv(raw)
+    return f"{int(rows_fnv(hashes.astype('<u8').view(np.uint8).reshape(1, -1))[0]):016x}"
