@@ -98,8 +98,18 @@ struct StepCounters {
 };
 
 PT_DEV v3 reciprocal3(v3 d) { return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
+// The reciprocal direction of a query: kept finite (a component of 0 gives +-2^90, not infinity), because the
+// grid-plane distances are multiply-adds in which 0 * infinity would be a NaN.  For a ray parallel to a pair of
+// slab planes the two distances are then huge and of opposite sign inside the slab, huge and of the same sign
+// outside it, which decides the box test as the infinities would.
+PT_DEV float finiteReciprocal(float d)
+{
+    const float big = 1.2379400392853803e27f;  // 2^90
+    return fmin_(fmax_(1.0f / d, -big), big);
+}
+PT_DEV v3 queryReciprocal3(v3 d) { return mk3(finiteReciprocal(d.x), finiteReciprocal(d.y), finiteReciprocal(d.z)); }
 
-// `inv` = reciprocal3(rd), for callers that have it at hand.
+// `inv` = queryReciprocal3(rd), for callers that have it at hand.
 PT_DEV void beginQuery(Query& q, int rootRef, v3 ro, v3 rd, v3 inv, bool isShadow)
 {
     q.ro = ro;
@@ -113,7 +123,7 @@ PT_DEV void beginQuery(Query& q, int rootRef, v3 ro, v3 rd, v3 inv, bool isShado
     q.leafPos = q.leafEnd;  // no leaf parked, whatever the previous query left
     q.isShadow = isShadow;
 }
-PT_DEV void beginQuery(Query& q, int rootRef, v3 ro, v3 rd, bool isShadow) { beginQuery(q, rootRef, ro, rd, reciprocal3(rd), isShadow); }
+PT_DEV void beginQuery(Query& q, int rootRef, v3 ro, v3 rd, bool isShadow) { beginQuery(q, rootRef, ro, rd, queryReciprocal3(rd), isShadow); }
 
 // What queryStep reports: the query goes on, it is complete (a closest-hit query's result is in best*,
 // a shadow query found no occluder), or a shadow query met an occluder (and is complete).
@@ -169,21 +179,15 @@ PT_DEV void stackPop(Query& q, const int* stack, const int* deep)
 // (`uniform`: both children are always opened instead, which at least halves the depth).  On the reference's
 // tree of the benchmark scene, whose builder caps its split cost, a ray then visits 6.0 nodes instead of 15.2.
 // Empty slots hold NaN boxes, which no ray enters.
-__global__ void collapseKernel(const DevNode* __restrict__ in, DevNode4* __restrict__ out, const int2* __restrict__ frontier,
+__global__ void collapseKernel(const DevNode* __restrict__ in, DevNodeQ* __restrict__ out, const int2* __restrict__ frontier,
                                unsigned count, int2* __restrict__ next, unsigned* __restrict__ counters, int uniform)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const int2 item = frontier[i];
     const DevNode n = in[item.x];
-    DevNode4 w;
-    for (int k = 0; k < 4; k++) {
-        w.child[k] = 0;
-        w.pad[k] = 0;
-        for (int a = 0; a < 3; a++) w.lo[a][k] = w.hi[a][k] = __builtin_nanf("");
-    }
     float mn[4][3], mx[4][3];
-    int ref[4];
+    int ref[4] = {0, 0, 0, 0};
     int used = 2;
     for (int a = 0; a < 3; a++) {
         mn[0][a] = n.lmin[a], mx[0][a] = n.lmax[a];
@@ -221,14 +225,56 @@ __global__ void collapseKernel(const DevNode* __restrict__ in, DevNode4* __restr
     for (int k = 0; k < used; k++) interior += ref[k] > 0;
     int dst = interior ? (int)atomicAdd(&counters[0], (unsigned)interior) : 0;
     int at = interior ? (int)atomicAdd(&counters[1], (unsigned)interior) : 0;
-    for (int k = 0; k < used; k++) {
-        int r = ref[k];
+    DevNodeQ w;
+    for (int k = 0; k < 4; k++) {
+        int r = k < used ? ref[k] : 0;
         if (r > 0) {
             next[at++] = make_int2(r, dst);
             r = dst++;
         }
         w.child[k] = r;
-        for (int a = 0; a < 3; a++) w.lo[a][k] = mn[k][a], w.hi[a][k] = mx[k][a];
+    }
+    // The grid: per axis the smallest power-of-two cell with which 256 planes span the children's boxes with
+    // kQuantMargin cells to spare on either side; every bound goes to the nearest plane outside it, then that many
+    // cells further out.  Containment is checked in double precision, where origin + q * cell is exact.
+    for (int a = 0; a < 3; a++) {
+        float lo = mn[0][a], hi = mx[0][a];
+        for (int k = 1; k < used; k++) lo = fmin_(lo, mn[k][a]), hi = fmax_(hi, mx[k][a]);
+        const double span = (double)hi - (double)lo;
+        const int cells = 255 - 2 * kQuantMargin - 1;  // (one more cell for the rounding of the origin)
+        float cell = 7.8886090522101181e-31f;          // 2^-100: any cell does for a flat node
+        if (span > 0.0) {
+            int e = 0;
+            (void)frexp(span / (double)cells, &e);  // span / cells = m * 2^e, 0.5 <= m < 1
+            e = e < -100 ? -100 : (e > 100 ? 100 : e);
+            cell = (float)ldexp(1.0, e);
+        }
+        unsigned wlo = 0, whi = 0;
+        for (int attempt = 0;; attempt++) {
+            const float origin = lo - (float)(kQuantMargin + 1) * cell;  // (rounds towards lo at worst: the checks below see it)
+            bool ok = (double)origin <= (double)lo;
+            wlo = 0, whi = 0;
+            for (int k = 0; k < 4 && ok; k++) {
+                long long ql = 255, qh = 0;  // an empty slot: inverted, entered by no ray
+                if (k < used) {
+                    ql = (long long)floor(((double)mn[k][a] - (double)origin) / (double)cell) - kQuantMargin;
+                    qh = (long long)ceil(((double)mx[k][a] - (double)origin) / (double)cell) + kQuantMargin;
+                    ql = ql < 0 ? 0 : ql;
+                    ok = qh <= 255 && (double)origin + (double)ql * (double)cell <= (double)mn[k][a] &&
+                         (double)origin + (double)qh * (double)cell >= (double)mx[k][a];
+                }
+                wlo |= (unsigned)(ql & 255) << (8 * k);
+                whi |= (unsigned)(qh & 255) << (8 * k);
+            }
+            if (ok || attempt > 300) {  // (boxes that are not finite never fit: the last grid tried stands)
+                w.origin[a] = origin;
+                break;
+            }
+            cell = cell * 2.0f;
+        }
+        w.scale[a] = cell;
+        w.qlo[a] = wlo;
+        w.qhi[a] = whi;
     }
     out[item.y] = w;
 }
@@ -243,34 +289,63 @@ PT_DEV int queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc, 
     // code and are all in flight before the first use.
     // (32-bit byte offsets from the array bases: the loads then take a scalar base and a 32-bit lane
     // offset, with no 64-bit address arithmetic in the loop; the host refuses arrays beyond 4 GB)
-    const unsigned nodeOff = (hasNode ? (unsigned)q.cur : 0u) << 7;
+    const unsigned nodeOff = (hasNode ? (unsigned)q.cur : 0u) << 6;
     const unsigned triIdx16 = (doTri ? q.leafPos : 0u) << 4;
     unsigned triOff;  // x 48 as one full-rate shift-add (the compiler would fold it into a quarter-rate 32-bit multiply)
     asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(triOff) : "v"(triIdx16));
-    static_assert(sizeof(DevNode4) == 128 && sizeof(DevTriangle) == 48, "record sizes are wired into the offsets above");
+    static_assert(sizeof(DevNodeQ) == 64 && sizeof(DevTriangle) == 48, "record sizes are wired into the offsets above");
     const float4* nrec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.wide) + nodeOff);
     const float4* trec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.triangles) + triOff);
-    const float4 lox = nrec[0], loy = nrec[1], loz = nrec[2], hix = nrec[3], hiy = nrec[4], hiz = nrec[5];
-    const int4 kids = *reinterpret_cast<const int4*>(nrec + 6);
+    const float4 n0 = nrec[0], n1 = nrec[1], n2 = nrec[2];  // origin xyz, cell x | cell yz, lower planes xy | lower z, upper xyz
+    const int4 kids = *reinterpret_cast<const int4*>(nrec + 3);
     const float4 t0 = trec[0], t1 = trec[1], t2 = trec[2];
     bool finished = false;  // query complete
     bool pop = false;
     if (hasNode) {
         if (COUNT) sc.nodeVisits++;
         const float limit = q.bestT * kPruneMargin;  // bestT stays FLT_MAX for shadow rays
-        float d0, d1, d2, d3, e0, e1, e2, e3;
-        const bool h0 = hitAabb(q.ro, q.inv, lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, d0, e0) & !(e0 > limit);
-        const bool h1 = hitAabb(q.ro, q.inv, lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, d1, e1) & !(e1 > limit);
-        const bool h2 = hitAabb(q.ro, q.inv, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, d2, e2) & !(e2 > limit);
-        const bool h3 = hitAabb(q.ro, q.inv, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, d3, e3) & !(e3 > limit);
-        // The nearest child entered, by the shader's box distance (intersection.glsl:169-180 orders its two children
-        // by the same value), is visited next and the others wait on the stack.  Three comparators over (distance,
+        // Slab tests of the four children against grid planes (intersection.glsl:63-77 tests the exact boxes; these
+        // contain them).  The ray is moved into the node's grid once -- t(plane p) = p * (cell * inv) + (origin - ro) * inv,
+        // one multiply-add per plane -- and the planes a ray meets first on each axis are picked by the sign of its
+        // direction, which also leaves the inverted box of an empty slot with its exit before its entry.
+        const float ax = (n0.x - q.ro.x) * q.inv.x, ay = (n0.y - q.ro.y) * q.inv.y, az = (n0.z - q.ro.z) * q.inv.z;
+        const float bx = n0.w * q.inv.x, by = n1.x * q.inv.y, bz = n1.y * q.inv.z;
+        const unsigned lox = __float_as_uint(n1.z), loy = __float_as_uint(n1.w), loz = __float_as_uint(n2.x);
+        const unsigned hix = __float_as_uint(n2.y), hiy = __float_as_uint(n2.z), hiz = __float_as_uint(n2.w);
+        const bool negx = q.inv.x < 0.0f, negy = q.inv.y < 0.0f, negz = q.inv.z < 0.0f;
+        const unsigned nearx = negx ? hix : lox, farx = negx ? lox : hix;
+        const unsigned neary = negy ? hiy : loy, fary = negy ? loy : hiy;
+        const unsigned nearz = negz ? hiz : loz, farz = negz ? loz : hiz;
+#define PT_PLANE(word, k, b, a) __builtin_fmaf((float)(((word) >> (8 * (k))) & 255u), b, a)
+        // A child is entered when the ray's segment [0, limit] and its three slab intervals overlap: the latest
+        // entry (0 and the three near planes) is no later than the earliest exit (the limit and the three far
+        // planes).  The children are ordered by that entry distance (the shader orders its two by the entry
+        // distance, or the exit distance when the origin is inside the box: the order decides nothing but which
+        // of two hits at exactly the same distance is found first).
+#define PT_CHILD(k, hit, dist)                                                                                                        \
+    {                                                                                                                                 \
+        const float e = fmax_(fmax_(fmax_(PT_PLANE(nearx, k, bx, ax), PT_PLANE(neary, k, by, ay)), PT_PLANE(nearz, k, bz, az)), 0.0f); \
+        const float x = fmin_(fmin_(fmin_(PT_PLANE(farx, k, bx, ax), PT_PLANE(fary, k, by, ay)), PT_PLANE(farz, k, bz, az)), limit);  \
+        dist = e;                                                                                                                     \
+        hit = e <= x;                                                                                                                 \
+    }
+        float d0, d1, d2, d3;
+        bool h0, h1, h2, h3;
+        PT_CHILD(0, h0, d0)
+        PT_CHILD(1, h1, d1)
+        PT_CHILD(2, h2, d2)
+        PT_CHILD(3, h3, d3)
+#undef PT_CHILD
+#undef PT_PLANE
+        // The nearest child entered is visited next and the others wait on the stack.  Three comparators over (distance,
         // reference) pairs, in which a child not entered is the farthest, bring the nearest to the front and leave
         // the rest half ordered (the larger of each first pair behind the smaller); finishing the sorting network
         // (two more comparators) visits no fewer nodes and costs 2 % on the reference's tree.  A push that is not one
         // writes the row above the stack's top, which nothing reads.
-        float k0 = h0 ? d0 : kFltMax, k1 = h1 ? d1 : kFltMax, k2 = h2 ? d2 : kFltMax, k3 = h3 ? d3 : kFltMax;
+        // (an empty slot has reference 0 and an inverted box; should a degenerate grid let a ray into it all the
+        // same, it must not pose as the nearest child: the keys go by the references)
         int r0 = h0 ? kids.x : 0, r1 = h1 ? kids.y : 0, r2 = h2 ? kids.z : 0, r3 = h3 ? kids.w : 0;
+        float k0 = r0 != 0 ? d0 : kFltMax, k1 = r1 != 0 ? d1 : kFltMax, k2 = r2 != 0 ? d2 : kFltMax, k3 = r3 != 0 ? d3 : kFltMax;
 #define PT_CSWAP(ka, ra, kb, rb)       \
     {                                  \
         const bool sw = kb < ka;       \
@@ -746,7 +821,7 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
                 pending = br.pending;
                 hasExt = br.hasExt;
                 extDir = br.extDir;
-                if (!PULL) extInv = reciprocal3(br.extDir);
+                if (!PULL) extInv = queryReciprocal3(br.extDir);
                 beginQuery(q, P.rootRef, br.origin, br.shadowDir, true);
                 mode = kModeTrav;
             } else if (br.hasExt) {

@@ -220,14 +220,14 @@ constexpr int kStackWavefront = 63;  // wavefront pipeline: all in LDS (64 rows 
 int collapseTree(pt_ctx* c, size_t nodeCount)
 {
     c->wideLevels = 0;
-    c->nodeBytes = 2 * sizeof(DevNode4);
-    HIP_TRY(c->dNodes4.ensure((nodeCount + 2) * sizeof(DevNode4)));
-    HIP_TRY(hipMemsetAsync(c->dNodes4.ptr, 0, 2 * sizeof(DevNode4), c->stream));  // node 0: idle lanes fetch it
+    c->nodeBytes = 2 * sizeof(DevNodeQ);
+    HIP_TRY(c->dNodes4.ensure((nodeCount + 2) * sizeof(DevNodeQ)));
+    HIP_TRY(hipMemsetAsync(c->dNodes4.ptr, 0, 2 * sizeof(DevNodeQ), c->stream));  // node 0: idle lanes fetch it
     if (c->rootRef <= 0) {  // the root is a leaf
         c->dNodes.release();
         return PT_OK;
     }
-    if ((nodeCount + 2) * sizeof(DevNode4) >= (1ull << 32))
+    if ((nodeCount + 2) * sizeof(DevNodeQ) >= (1ull << 32))
         return fail(PT_ERR_SCENE, "node array of 4 GB or more (the kernels address records by 32-bit byte offsets)");
     ScopedBuffer frontier[2], counters;
     HIP_TRY(frontier[0].ensure(nodeCount * sizeof(int2)));
@@ -245,7 +245,7 @@ int collapseTree(pt_ctx* c, size_t nodeCount)
         while (count > 0) {
             HIP_TRY(hipMemcpyAsync(counters.ptr, h, 8, hipMemcpyHostToDevice, c->stream));
             hipLaunchKernelGGL(collapseKernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, (const DevNode*)c->dNodes.ptr,
-                               (DevNode4*)c->dNodes4.ptr, (const int2*)frontier[cur].ptr, count, (int2*)frontier[cur ^ 1].ptr,
+                               (DevNodeQ*)c->dNodes4.ptr, (const int2*)frontier[cur].ptr, count, (int2*)frontier[cur ^ 1].ptr,
                                (unsigned*)counters.ptr, uniform);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(h, counters.ptr, 8, hipMemcpyDeviceToHost, c->stream));
@@ -265,7 +265,7 @@ int collapseTree(pt_ctx* c, size_t nodeCount)
     if (3 * c->wideLevels > kStackLds + kStackPrivate)
         return fail(PT_ERR_SCENE, "BVH too deep: " + std::to_string(c->wideLevels) + " levels of four-wide nodes, the traversal stack holds " +
                                       std::to_string((kStackLds + kStackPrivate) / 3));
-    c->nodeBytes = (size_t)wideCount * sizeof(DevNode4);
+    c->nodeBytes = (size_t)wideCount * sizeof(DevNodeQ);
     c->dNodes.release();
     return PT_OK;
 }
@@ -522,7 +522,7 @@ void fillLaunchBlocks(const pt_ctx* c, uint32_t frameFirst, uint32_t frameCount,
 
     S = DevScene{};
     S.nodes = (const DevNode*)c->dNodes.ptr;
-    S.wide = (const DevNode4*)c->dNodes4.ptr;
+    S.wide = (const DevNodeQ*)c->dNodes4.ptr;
     S.triangles = (const DevTriangle*)c->dTriangles.ptr;
     S.shading = (const DevShading*)c->dShading.ptr;
     S.materials = (const DevMaterial*)c->dMaterials.ptr;

@@ -25,7 +25,7 @@ constexpr float kMinDielectricsF0 = 0.04f;
 
 struct DevScene {
     const DevNode* nodes;
-    const DevNode4* wide;  // the same tree with every other level folded away
+    const DevNodeQ* wide;  // the four-wide tree the traversal walks (boxes quantised outward)
     const DevTriangle* triangles;
     const DevShading* shading;
     const DevMaterial* materials;

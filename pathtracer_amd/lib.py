@@ -3,7 +3,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptcore.so")
+# PT_LIBPTCORE: another build of the library (A/B measurements of kernel variants: tools/ab_libs.py)
+LIB_PATH = os.environ.get("PT_LIBPTCORE") or os.path.join(_HERE, "libptcore.so")
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 
