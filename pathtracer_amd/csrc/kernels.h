@@ -504,25 +504,34 @@ PT_DEV BounceRays shadeHit(const DevParams& P, const DevScene& S, PathState& ps,
     out.hasShadow = false;
     out.hasExt = false;
     out.origin = out.shadowDir = out.extDir = out.pending = splat(0.0f);
+    // The block's reads form two rounds instead of four: the shading record and the table entries of the light
+    // direction (SampleHdri's two randoms are the bounce's first: pathtracing.comp:65) are requested together, then the
+    // material record and the light's radiance and pdf (EvaluateHdri, taken for every lane: whether it counts is
+    // decided further down by N.L, which needs the material's normal map first).
     // hit attributes of the winning triangle (intersection.glsl:41-57)
     const float w = 1.0f - uHit - vHit;
     const v3 P0 = ro + rd * tHit;
     const float4* shp = reinterpret_cast<const float4*>(S.shading + prim);
     const float4 s0 = shp[0], s1 = shp[1], s2 = shp[2], s3 = shp[3], s4 = shp[4];
+    const v3 Ll = sampleHdri(S, P.envW, P.envH, ps.rng);
     const float uvx = s0.w * w + s2.w * uHit + s3.y * vHit;
     const float uvy = s1.w * w + s3.x * uHit + s3.z * vHit;
     v3 N = normalize3(mk3(s0.x, s0.y, s0.z) * w + mk3(s1.x, s1.y, s1.z) * uHit + mk3(s2.x, s2.y, s2.z) * vHit);
     const v3 Ng = mk3(s4.x, s4.y, s4.z);
     const unsigned meshIndex = __float_as_uint(s3.w);
+    const MaterialWords mw = loadMaterial(S, meshIndex);
+    const int normalMap = S.materials[meshIndex].tex[kTexNormal];
+    float pdfLight = 0.0f;
+    const v3 colorLight = evaluateHdri(S, P.envW, P.envH, P.hdriW, P.hdriH, Ll, pdfLight);
     v3 tangent = splat(0.0f);
-    if (S.materials[meshIndex].tex[kTexNormal] >= 0) {
+    if (normalMap >= 0) {
         const float4* tp = reinterpret_cast<const float4*>(S.triangles + prim);
         const float4 q1 = tp[1], q2 = tp[2];
         const float dBx = s2.w - s0.w, dBy = s3.x - s1.w, dCx = s3.y - s0.w, dCy = s3.z - s1.w;
         const float invTd = 1.0f / (dBx * dCy - dBy * dCx);
         tangent = (mk3(q1.x, q1.y, q1.z) * dCy - mk3(q2.x, q2.y, q2.z) * dBy) * invTd;
     }
-    const MaterialEval me = evaluateMaterial(S, P, meshIndex, uvx, uvy, N, tangent);
+    const MaterialEval me = evaluateMaterial(S, P, mw, meshIndex, uvx, uvy, N, tangent);
     const v3 V = -rd;
     const Surface surf = makeSurface(me, N, V);
     ps.radiance = ps.radiance + ps.throughput * surf.emission;
@@ -530,10 +539,7 @@ PT_DEV BounceRays shadeHit(const DevParams& P, const DevScene& S, PathState& ps,
 
     // next-event estimation towards the HDRI (pathtracing.comp:64-102), everything but the
     // occlusion test itself
-    const v3 Ll = sampleHdri(S, P.envW, P.envH, ps.rng);
     if (dot(N, Ll) > 0.0f) {
-        float pdfLight = 0.0f;
-        v3 colorLight = evaluateHdri(S, P.envW, P.envH, P.hdriW, P.hdriH, Ll, pdfLight);
         const Dir dl = makeDir(surf, Ll);
         float pdfNee = 0.0f;
         const v3 fNee = evaluateBsdf(surf, dl, pdfNee);

@@ -219,12 +219,22 @@ struct MaterialEval {
         clearcoatRoughness, refraction, transmission;
 };
 
-// `shadingNormal` is rewritten when a normal map is bound (utility.glsl:108-111).
-PT_DEV MaterialEval evaluateMaterial(const DevScene& S, const DevParams& P, unsigned meshIndex, float u, float v,
-                                     v3& shadingNormal, v3 tangent)
+// The material record's scalar part as loaded (requested as early as the hit's material index is known, so that
+// the reads are under way while the caller does other work).
+struct MaterialWords {
+    float4 m0, m1, m2, m3, m4;
+};
+PT_DEV MaterialWords loadMaterial(const DevScene& S, unsigned meshIndex)
 {
     const float4* mp = (const float4*)(S.materials + meshIndex);
-    float4 m0 = mp[0], m1 = mp[1], m2 = mp[2], m3 = mp[3], m4 = mp[4];
+    return MaterialWords{mp[0], mp[1], mp[2], mp[3], mp[4]};
+}
+
+// `shadingNormal` is rewritten when a normal map is bound (utility.glsl:108-111).
+PT_DEV MaterialEval evaluateMaterial(const DevScene& S, const DevParams& P, const MaterialWords& mw, unsigned meshIndex, float u,
+                                     float v, v3& shadingNormal, v3 tangent)
+{
+    const float4 m0 = mw.m0, m1 = mw.m1, m2 = mw.m2, m3 = mw.m3, m4 = mw.m4;
     MaterialEval e;
     e.emission = mk3(m0.x, m0.y, m0.z);
     e.specular = m0.w;
