@@ -223,8 +223,9 @@ def pmc_summary(args, W, H, S):
         except Exception:
             continue
         shape = (t.get("scene"), t.get("width"), t.get("height"), t.get("spp_per_step"), t.get("max_bounces"), t.get("subdivide"),
-                 t.get("bvh"), t.get("copies"))
-        if shape == (args.scene, W, H, S, args.bounces, args.subdivide, args.bvh, args.copies):
+                 t.get("bvh"), t.get("copies"), int(t.get("rebuild", 0)))
+        rebuilt = int(args.bvh != "device" and not getattr(args, "no_rebuild", False))
+        if shape == (args.scene, W, H, S, args.bounces, args.subdivide, args.bvh, args.copies, rebuilt):
             return t
     return None
 
@@ -245,11 +246,14 @@ def main():
                     help="instanced-scene stress: this many bunnies flattened on a jittered grid (139 = 20 M triangles)")
     ap.add_argument("--bvh", choices=["host", "full-sweep", "device"], default="host",
                     help="host: the reference's sweep-SAH builder (bit-identical tree); device: GPU builder")
+    ap.add_argument("--no-rebuild", action="store_true",
+                    help="traverse the uploaded tree itself (pt_set_bvh_rebuild(ctx, 0)); by default the library checks it and "
+                         "builds its own over the uploaded primitives on the GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frame-by-frame", action="store_true",
                     help="skip the extra run of 64 one-sample dispatch calls (frame_by_frame)")
     ap.add_argument("--no-device-tree", action="store_true",
-                    help="skip the extra measurement on the GPU-built tree (profiling runs: one tree per kernel name)")
+                    help="skip the extra measurement on the uploaded tree itself (profiling runs: one tree per kernel name)")
     ap.add_argument("--reduce-every-step", action="store_true", help="N > 1: all-reduce after every step, not once per render")
     ap.add_argument("--tuning", default="", help="scheduler settings for A/B runs: key=value,key=value (Renderer.set_tuning)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # launcher test on CPU: gloo, no renderer
@@ -318,6 +322,8 @@ def main():
         g = sr.renderer
         if args.tuning:  # before the scene goes in: some settings steer the device BVH builder
             g.set_tuning(**{k: int(v) for k, v in (item.split("=") for item in args.tuning.split(","))})
+        if args.no_rebuild:
+            g.set_bvh_rebuild(False)
         install_scene(g, work)
         params = scene_params(work, W, H, args.bounces)
         sr.set_params(params)
@@ -427,14 +433,20 @@ def main():
             "config": {
                 "workload": ("stub renderer (launcher test)" if args.stub else
                              what + f"{W}x{H}, max {args.bounces} bounces, {S} spp per step per GPU, analytic sky HDRI 1024x512, "
-                             "BVH built by the " + {"device": "GPU clustering builder", "host": "sweep-SAH host builder (the reference tree)",
-                                                      "full-sweep": "sweep-SAH host builder without the reference's cost cap"}[args.bvh]),
+                             "BVH " + {"device": "built by the GPU clustering builder from the triangle soup",
+                                       "host": "uploaded from the sweep-SAH host builder (the reference's tree)",
+                                       "full-sweep": "uploaded from the sweep-SAH host builder without the reference's cost cap"}[args.bvh] +
+                             ("" if args.bvh == "device" else
+                              ", traversed as uploaded (rebuild off)" if args.no_rebuild else
+                              "; the library checks the uploaded tree and traverses its own, built on the GPU over the uploaded "
+                              "primitives (its default, pt_set_bvh_rebuild)")),
                 "scene": args.scene, "width": W, "height": H, "max_bounces": args.bounces, "spp_per_step_per_gpu": S,
                 "total_spp": total_spp, "parallelism": f"sample-sharded x{world}" if world > 1 else "single GPU",
                 "reduce": ("none (one GPU)" if world == 1 else
                            "REHEARSAL over gloo with ranks sharing GPUs: not a measurement" if backend != "nccl" and not args.stub else
                            "one RCCL all-reduce per step" if args.reduce_every_step else "one RCCL all-reduce per render (after the last step, timed)"),
                 "bvh_build_seconds": round(work["bvh_seconds"], 3),
+                "tree_traversed": "device-built" if (args.bvh == "device" or not args.no_rebuild) else "as uploaded",
             },
             "roofline": {
                 # `achieved` = ALGORITHMIC bytes per launch over the trace kernel's HIP-event time, measured in this run.
@@ -501,13 +513,13 @@ def main():
                 out["frame_by_frame"] = {"error": str(e)}
             finally:
                 g.set_stream(sr.stream.cuda_stream)
-        if world == 1 and args.bvh == "host" and args.copies == 1 and not args.no_device_tree and not args.stub:
-            # Outside the timed region, for the record: the same steps on the tree the GPU builder makes
-            # of the same triangles (the reference's builder caps its split cost; see --bvh).
+        if world == 1 and args.bvh == "host" and args.copies == 1 and not args.no_device_tree and not args.no_rebuild and not args.stub:
+            # Outside the timed region, for the record: the same steps with the uploaded tree itself traversed
+            # (pt_set_bvh_rebuild(ctx, 0)): the reference's builder caps its split cost, see --bvh.
             try:
-                t0 = time.time()
-                g.build_bvh_device(work["prims"])
-                t_build = time.time() - t0
+                g.set_bvh_rebuild(False)
+                g.upload_nodes(work["nodes"])
+                g.upload_primitives(work["prims"])
                 sr.clear()
                 sr.render_step(0, S)
                 g.synchronize()
@@ -518,10 +530,10 @@ def main():
                     alt_rays += st2.rays_closest + st2.rays_any
                 g.synchronize()
                 dt = time.perf_counter() - t1
-                out["device_built_tree"] = {"value": alt_rays / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt / args.steps * 1e3,
-                                            "bvh_build_seconds": round(t_build, 3)}
+                out["uploaded_tree_traversed"] = {"value": alt_rays / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt / args.steps * 1e3,
+                                                  "note": "pt_set_bvh_rebuild(ctx, 0): the reference builder's tree as uploaded"}
             except Exception as e:  # never lose the benchmark line over the extra measurement
-                out["device_built_tree"] = {"error": str(e)}
+                out["uploaded_tree_traversed"] = {"error": str(e)}
         if not args.no_cpu_baseline and world == 1 and not args.stub:
             threads = min(16, os.cpu_count() or 1)
             try:

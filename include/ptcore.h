@@ -133,11 +133,13 @@ int pt_upload_nodes(pt_ctx* ctx, const void* nodes48, size_t count);
 /* SSBO binding 3 (PathTracingRenderer.cpp:615-662): BvhPrimitiveAlign records of 112 B in
  * post-build order. */
 int pt_upload_primitives(pt_ctx* ctx, const void* prims112, size_t count);
-/* No counterpart in the reference.  With enable != 0 the tree handed to pt_upload_nodes is checked
+/* No counterpart in the reference.  By default (enable != 0) the tree handed to pt_upload_nodes is checked
  * but not traversed: the GPU builder (pt_build_bvh_device) makes its own over the primitives of
- * pt_upload_primitives at the next dispatch.  For a host that keeps calling the reference's
- * BVH::BuildBvhWithSah, whose capped split cost gives trees that take 2-3x the node visits per ray:
- * one call, no other change, images equal except where hit distances tie exactly.  Off by default. */
+ * pt_upload_primitives at the next dispatch (milliseconds).  The reference's BVH::BuildBvhWithSah caps its
+ * split cost and cuts the top of any sizeable scene at the median along X, which costs 1.1-4x the node
+ * visits per ray; a host that keeps calling it gets the better tree with no change on its side, and the
+ * same images (the tree only decides where rays look; equal except where two hit distances tie exactly).
+ * enable = 0: the uploaded tree itself is folded and traversed.  pt_download_bvh returns the tree in use. */
 int pt_set_bvh_rebuild(pt_ctx* ctx, int enable);
 /* SSBO binding 1 (PathTracingRenderer.cpp:509-564): MaterialAlign records of 176 B.  The 11
  * 64-bit bindless handles are reinterpreted as 1-based slots of pt_upload_texture

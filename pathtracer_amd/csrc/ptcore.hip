@@ -161,7 +161,7 @@ struct pt_ctx {
     uint32_t lastSlots = 0;  // resident waves of the most recent megakernel launch's variant
     uint64_t sampleBudgetBytes = 8ull << 30;
     int wavesPerSimd = 0;      // megakernel variant: 3 or 4 waves per SIMD (0: the default, 3)
-    bool rebuildOnUpload = false;  // pt_upload_nodes' tree is replaced by the device builder's over the same primitives
+    bool rebuildOnUpload = true;  // pt_upload_nodes' tree is checked, then replaced by the device builder's over the same primitives
     int plocRadius = 32;  // device BVH builder: neighbours searched on either side per clustering round (0: Morton radix tree)
     bool pullItems = true;  // megakernel: resident waves pull the work items (else one block per item)
     size_t waveTimeCount = 0;

@@ -61,6 +61,6 @@ def test_pmc_summary_is_made_of_the_committed_counters_and_found_by_launch_shape
         {k: t[k] for k in ("scene", "width", "height", "spp_per_step", "max_bounces", "subdivide", "bvh", "copies")}
     sys.path.insert(0, ROOT)
     import bench
-    args = argparse.Namespace(scene="dragonglass", bounces=8, subdivide=1, bvh="host", copies=1)
+    args = argparse.Namespace(scene="dragonglass", bounces=8, subdivide=1, bvh="host", copies=1, no_rebuild=True)
     assert bench.pmc_summary(args, 1920, 1080, 64)["bytes_per_launch"] == committed["bytes_per_launch"]
     assert bench.pmc_summary(args, 1280, 720, 64) is None  # another launch shape: the counters do not apply

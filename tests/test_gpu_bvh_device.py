@@ -58,6 +58,7 @@ def test_device_built_tree_is_valid_and_renders_like_the_oracle(recipe, radius):
     _assert_images_equal(gpu, cpu[:3], cpu[3], f"{recipe} on the device-built BVH")
     # the same tree through the host packer (pt_upload_nodes / pt_upload_primitives): same images
     h = R.Renderer(width, height)
+    h.set_bvh_rebuild(False)  # walk the uploaded tree itself
     h.upload_nodes(nodes)
     h.upload_primitives(prims)
     gpu2, _ = _render_pair(nodes, prims, mats, width, height, 8 if recipe == "BunnyGlass" else 3, h)
@@ -174,6 +175,7 @@ def test_full_sweep_tree_renders_like_the_oracle_and_like_the_reference_tree():
         sorted_prims, nodes40 = R.build_bvh_sah(prims100, 4, full_sweep=full)
         nodes, prims = R.align_nodes(nodes40), R.align_primitives(sorted_prims)
         g = R.Renderer(width, height)
+        g.set_bvh_rebuild(False)  # the uploaded trees themselves are what is compared
         g.upload_nodes(nodes)
         g.upload_primitives(prims)
         gpu, cpu = _render_pair(nodes, prims, mats, width, height, 8, g)
@@ -185,8 +187,9 @@ def test_full_sweep_tree_renders_like_the_oracle_and_like_the_reference_tree():
 
 
 def test_rebuild_on_upload_keeps_the_image_and_cuts_the_visits():
-    """pt_set_bvh_rebuild: the reference's tree is uploaded as usual, the device builder's tree over the
-    same primitives is traversed.  Same image (up to exact distance ties), fewer node visits per ray."""
+    """pt_set_bvh_rebuild (on unless switched off): the reference's tree is uploaded as usual, the device
+    builder's tree over the same primitives is traversed.  Same image (up to exact distance ties), fewer node
+    visits per ray."""
     from tests.common import built_scene
     nodes, prims, mats = built_scene("BunnyGlass")
     hdri, cache = environment(256, 128)
@@ -194,9 +197,10 @@ def test_rebuild_on_upload_keeps_the_image_and_cuts_the_visits():
     p = R.default_params(width, height)
     p.max_bounces = 8
     images, visits = {}, {}
-    for rebuild in (False, True):
+    for rebuild in (False, True, None):  # None: the library's default
         g = R.Renderer(width, height)
-        g.set_bvh_rebuild(rebuild)
+        if rebuild is not None:
+            g.set_bvh_rebuild(rebuild)
         g.upload_nodes(nodes)
         g.upload_primitives(prims)
         g.upload_materials(mats)
@@ -217,4 +221,5 @@ def test_rebuild_on_upload_keeps_the_image_and_cuts_the_visits():
     for a, b in zip(images[False], images[True]):
         differing = int(np.any(a.view(np.uint32) != b.view(np.uint32), axis=-1).sum())
         assert differing <= 1e-4 * width * height, differing
+    assert visits[None] == visits[True] and images[None][0].tobytes() == images[True][0].tobytes()  # the default is to rebuild
     assert visits[True] < 0.8 * visits[False], visits  # (four-wide nodes folded by surface area hide much of the capped sweep's cost)

@@ -449,6 +449,7 @@ def test_debug_views_are_the_shaders_debug_output():
     tree deep enough to overflow the shader's 16-entry stack: purple) and the HDRI-cache view."""
     w, h = 160, 96
     o, g = _pair("BunnyClearcoat", w, h)
+    g.set_bvh_rebuild(False)  # the view shows the tree in use: here the uploaded one, which the oracle walks too
     p = R.default_params(w, h)
     g.set_params(p)
     heat = g.debug_view(1)
@@ -627,6 +628,7 @@ def test_tree_whose_fold_by_area_is_too_deep_is_folded_level_by_level():
     images = {}
     for name, (n40, p100) in {"caterpillar": (nodes40, prims), "sah": (sah_nodes, sorted_prims)}.items():
         g = R.Renderer(96, 64)
+        g.set_bvh_rebuild(False)  # this test is about the uploaded tree itself
         g.upload_nodes(R.align_nodes(n40))
         g.upload_primitives(R.align_primitives(p100))
         g.upload_materials(mats)
@@ -756,6 +758,7 @@ def test_traversal_stack_beyond_32_entries(pipeline):
         "sah": (sah_nodes, sorted_prims, dict()),
     }.items():
         g = R.Renderer(96, 64)
+        g.set_bvh_rebuild(False)  # the uploaded chain is what drives the stack deep
         g.set_tuning(pipeline=pipeline, **tuning)
         g.upload_nodes(R.align_nodes(n40))
         g.upload_primitives(R.align_primitives(p100))

@@ -17,6 +17,7 @@ from pathtracer_amd import renderer as R
 class A: subdivide = bench.DEFAULT_SUBDIVIDE; bvh = os.environ.get("PT_AB_BVH", "host")
 work = bench.build_workload(A)
 g = R.Renderer(1920, 1080)
+g.set_bvh_rebuild(os.environ.get("PT_AB_REBUILD", "0") == "1")  # the uploaded tree itself unless asked otherwise
 if work["nodes"] is None: g.build_bvh_device(work["prims"])
 else: g.upload_nodes(work["nodes"]); g.upload_primitives(work["prims"])
 g.upload_materials(work["mats"]); g.upload_environment(work["hdri"], work["cache"])

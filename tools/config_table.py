@@ -20,6 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--spp", type=int, default=64)
 ap.add_argument("--bvh", choices=["host", "full-sweep", "device"], default="host",
                 help="host: the reference's builder; full-sweep: the same without its cost cap; device: GPU linear BVH")
+ap.add_argument("--no-rebuild", action="store_true", help="traverse the host builder's tree itself (pt_set_bvh_rebuild off)")
 ap.add_argument("--depths", action="store_true", help="also print the share of paths alive at each depth (counting build)")
 ap.add_argument("--tuning", default="", help="scheduler settings: key=value,key=value (Renderer.set_tuning)")
 args = ap.parse_args()
@@ -32,6 +33,8 @@ def run(name, width, height, bounces, meshes, mats, textures=(), eye=None, look_
     g = R.Renderer(width, height)
     if args.tuning:  # before the scene goes in: some settings steer the device BVH builder
         g.set_tuning(**{k: int(v) for k, v in (item.split("=") for item in args.tuning.split(","))})
+    if args.no_rebuild:
+        g.set_bvh_rebuild(False)
     for slot, texels, srgb in textures:
         g.upload_texture(slot, texels, srgb)
     for (v, i), m in zip(meshes, mats):

@@ -20,9 +20,10 @@ step bench_c5 400 python3 bench.py --scene spheres
 step bench_c5_wavefront 400 python3 bench.py --scene spheres --tuning pipeline=1 --no-cpu-baseline --no-device-tree --no-frame-by-frame --steps 2 --spp-per-step 16
 step bench_c5_megakernel16 400 python3 bench.py --scene spheres --no-cpu-baseline --no-device-tree --steps 2 --spp-per-step 16
 step bench_c4 600 python3 bench.py $C4 --no-cpu-baseline
-step config_table_host 400 python3 tools/config_table.py --depths
+step config_table_default 400 python3 tools/config_table.py --depths
+step config_table_host 400 python3 tools/config_table.py --no-rebuild
 step config_table_device 400 python3 tools/config_table.py --bvh device
-step config_table_full-sweep 500 python3 tools/config_table.py --bvh full-sweep
+step config_table_full-sweep 500 python3 tools/config_table.py --bvh full-sweep --no-rebuild
 step occupancy 200 python3 tools/occupancy_profile.py 64
 echo "== profiles"
 bash tools/profile_gpu.sh ${TAG}_c2 > "$OUT/profile_c2.log" 2>&1 || { echo "profile c2 failed"; tail -5 "$OUT/profile_c2.log"; exit 1; }

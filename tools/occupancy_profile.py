@@ -18,6 +18,7 @@ class A:
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 work = bench.build_workload(A)
 g = R.Renderer(1920, 1080)
+g.set_bvh_rebuild(os.environ.get("PT_PROFILE_REBUILD", "1") == "1")
 if work["nodes"] is None:
     g.build_bvh_device(work["prims"])
 else:
