@@ -348,10 +348,10 @@ int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, 
 /* Tuning hook, not part of the drop-in surface (no counterpart in the reference).  key 0: scheduler
  * (0 = single-launch megakernel, the default; 1 = wavefront pipeline, which takes trees of at most 21
  * four-wide levels where the megakernel takes 32: select it before the upload so that the fold aims for that); 1: megakernel traversal-phase
- * exit threshold in 64ths of the lanes that entered the phase (default 32); 2: wavefront refill threshold in idle
+ * exit threshold in 64ths of the lanes that entered the phase (default 28); 2: wavefront refill threshold in idle
  * lanes (default 16); 3: wavefront iterations between read-backs of the live-ray count (default 2);
  * 4: traverse grid size in blocks (0 = sized from the occupancy query); 5: megakernel hit-shading
- * threshold in 64ths of the live lanes (default 16): hits wait until that share of the wave holds one;
+ * threshold in 64ths of the live lanes (default 28): hits wait until that share of the wave holds one;
  * 6: costliest-block-first launch order from the previous launch's per-tile cost (default 1); 7: tile
  * split: a tile whose cost exceeds 1/value of the launch's lower bound (total cost / resident waves) has
  * its samples spread over several work items; 0 = one item per tile; -1 (default) = 8 for images with
@@ -363,7 +363,8 @@ int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, 
  * 11: megakernel variant compiled for 3 or 4 resident waves per SIMD (default 0: 3); 12: the trace launches
  * of consecutive pt_dispatch calls may overlap, the next call's waves filling the chip while the last waves of
  * the call before run dry (1), never do (0), or do for calls of at most 8 frames (-1, the default); calls
- * overlap on the library's own stream only, never on one set with pt_set_stream. */
+ * overlap on the library's own stream only, never on one set with pt_set_stream; 13: device BVH builder: most
+ * triangles per leaf, 1..4 (default 0: 2 for scenes of up to 1.3 M triangles, which the caches hold, 4 above). */
 int pt_debug_set_tuning(pt_ctx* ctx, int key, int value);
 
 /* Profiling hook, not part of the drop-in surface (no counterpart in the reference): wave-level

@@ -98,14 +98,16 @@ struct StepCounters {
 };
 
 PT_DEV v3 reciprocal3(v3 d) { return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
-// The reciprocal direction of a query: kept finite (a component of 0 gives +-2^90, not infinity), because the
-// grid-plane distances are multiply-adds in which 0 * infinity would be a NaN.  For a ray parallel to a pair of
-// slab planes the two distances are then huge and of opposite sign inside the slab, huge and of the same sign
-// outside it, which decides the box test as the infinities would.
+// The reciprocal direction of a query, for the box tests alone (the triangle test divides exactly): the
+// hardware's approximate reciprocal (1 ulp, one instruction where the correctly rounded division takes ten),
+// kept finite (a component of 0 gives +-2^90, not infinity), because the grid-plane distances are
+// multiply-adds in which 0 * infinity would be a NaN.  For a ray parallel to a pair of slab planes the two
+// distances are then huge and of opposite sign inside the slab, huge and of the same sign outside it, which
+// decides the box test as the infinities would.
 PT_DEV float finiteReciprocal(float d)
 {
     const float big = 1.2379400392853803e27f;  // 2^90
-    return fmin_(fmax_(1.0f / d, -big), big);
+    return fmin_(fmax_(__builtin_amdgcn_rcpf(d), -big), big);
 }
 PT_DEV v3 queryReciprocal3(v3 d) { return mk3(finiteReciprocal(d.x), finiteReciprocal(d.y), finiteReciprocal(d.z)); }
 
@@ -298,11 +300,26 @@ PT_DEV int queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc, 
     const float4* trec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.triangles) + triOff);
     const float4 n0 = nrec[0], n1 = nrec[1], n2 = nrec[2];  // origin xyz, cell x | cell yz, lower planes xy | lower z, upper xyz
     const int4 kids = *reinterpret_cast<const int4*>(nrec + 3);
+#ifdef PT_EXPERIMENT_EXTRA_LOAD  // what one more 16-byte read per node visit costs
+    const float4 extraRead = nrec[4 + PT_EXPERIMENT_EXTRA_LOAD];
+#endif
     const float4 t0 = trec[0], t1 = trec[1], t2 = trec[2];
     bool finished = false;  // query complete
     bool pop = false;
     if (hasNode) {
         if (COUNT) sc.nodeVisits++;
+#ifdef PT_EXPERIMENT_EXTRA_LOAD
+        asm volatile("" ::"v"(extraRead.x));
+#endif
+#ifdef PT_EXPERIMENT_EXTRA_VALU  // what this many more vector instructions per node visit cost
+        {
+            float e0 = q.ro.x, e1 = q.ro.y, e2 = q.ro.z, e3 = q.rd.x;
+            for (int i = 0; i < PT_EXPERIMENT_EXTRA_VALU / 4; i++)
+                asm volatile("v_add_f32 %0, %0, %0\n\tv_add_f32 %1, %1, %1\n\tv_add_f32 %2, %2, %2\n\tv_add_f32 %3, %3, %3"
+                             : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
+            asm volatile("" ::"v"(e0), "v"(e1), "v"(e2), "v"(e3));
+        }
+#endif
         const float limit = q.bestT * kPruneMargin;  // bestT stays FLT_MAX for shadow rays
         // Slab tests of the four children against grid planes (intersection.glsl:63-77 tests the exact boxes; these
         // contain them).  The ray is moved into the node's grid once -- t(plane p) = p * (cell * inv) + (origin - ro) * inv,
@@ -480,49 +497,59 @@ PT_DEV void startSample(const DevParams& P, unsigned px, unsigned py, PathState&
     ps.bounce = 0;
 }
 
-// The ray (.., rd) left the scene at bounce ps.bounce: environment radiance with MIS against the
-// BSDF sample that produced the ray (pathtracing.comp:36-52).  The path ends here.
-PT_DEV void shadeMiss(const DevParams& P, const DevScene& S, PathState& ps, v3 rd)
-{
-    float pdfLight = 0.0f;
-    v3 colorLight = evaluateHdri(S, P.envW, P.envH, P.hdriW, P.hdriH, rd, pdfLight);
-    float misWeight = 1.0f;
-    if (ps.bounce > 0u) {
-        float t = ps.pdfBsdf * ps.pdfBsdf;
-        misWeight = t / (pdfLight * pdfLight + t);
-    }
-    if (misWeight > 0.0f) ps.radiance = ps.radiance + misWeight * ps.throughput * colorLight * ps.f / ps.pdfBsdf;
-}
-
-// One iteration of PathTrace's bounce loop (pathtracing.comp:25-140) around the closest hit
-// (prim, t, u, v) of the ray (ro, rd).  Updates the path state and returns the rays the bounce
-// wants traced.  No ray at all means the path has ended.
-PT_DEV BounceRays shadeHit(const DevParams& P, const DevScene& S, PathState& ps, v3 ro, v3 rd, int prim, float tHit,
-                           float uHit, float vHit)
+// One ray's shading, for a lane whose closest-hit query ended in a miss (`isHit` false: the ray (.., rd) left the scene
+// at bounce ps.bounce, environment radiance with MIS against the BSDF sample that produced the ray,
+// pathtracing.comp:36-52, and the path ends) or in a hit (`isHit`: one iteration of PathTrace's bounce loop,
+// pathtracing.comp:25-140, around the closest hit (prim, t, u, v) of the ray (ro, rd); updates the path state and
+// returns the rays the bounce wants traced, none at all meaning that the path has ended).  Both kinds of lane go
+// through ONE environment lookup -- a miss looks along its ray, a hit towards the light direction it has just
+// sampled -- so that a wave with lanes of either kind pays for that code once, at the fill of both together.
+PT_DEV BounceRays shadeRay(const DevParams& P, const DevScene& S, PathState& ps, v3 ro, v3 rd, int prim, float tHit, float uHit,
+                           float vHit, bool isHit)
 {
     BounceRays out;
     out.hasShadow = false;
     out.hasExt = false;
     out.origin = out.shadowDir = out.extDir = out.pending = splat(0.0f);
-    // The block's reads form two rounds instead of four: the shading record and the table entries of the light
-    // direction (SampleHdri's two randoms are the bounce's first: pathtracing.comp:65) are requested together, then the
-    // material record and the light's radiance and pdf (EvaluateHdri, taken for every lane: whether it counts is
-    // decided further down by N.L, which needs the material's normal map first).
-    // hit attributes of the winning triangle (intersection.glsl:41-57)
-    const float w = 1.0f - uHit - vHit;
-    const v3 P0 = ro + rd * tHit;
-    const float4* shp = reinterpret_cast<const float4*>(S.shading + prim);
-    const float4 s0 = shp[0], s1 = shp[1], s2 = shp[2], s3 = shp[3], s4 = shp[4];
-    const v3 Ll = sampleHdri(S, P.envW, P.envH, ps.rng);
-    const float uvx = s0.w * w + s2.w * uHit + s3.y * vHit;
-    const float uvy = s1.w * w + s3.x * uHit + s3.z * vHit;
-    v3 N = normalize3(mk3(s0.x, s0.y, s0.z) * w + mk3(s1.x, s1.y, s1.z) * uHit + mk3(s2.x, s2.y, s2.z) * vHit);
-    const v3 Ng = mk3(s4.x, s4.y, s4.z);
-    const unsigned meshIndex = __float_as_uint(s3.w);
-    const MaterialWords mw = loadMaterial(S, meshIndex);
-    const int normalMap = S.materials[meshIndex].tex[kTexNormal];
+    // A hit's reads form two rounds instead of four: the shading record and the table entries of the light direction
+    // (SampleHdri's two randoms are the bounce's first: pathtracing.comp:65) are requested together, then the material
+    // record and the light's radiance and pdf (EvaluateHdri, taken for every hit: whether it counts is decided further
+    // down by N.L, which needs the material's normal map first).
+    float4 s0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), s1 = s0, s2 = s0, s3 = s0;
+    v3 N = splat(0.0f), Ng = splat(0.0f), P0 = splat(0.0f);
+    float uvx = 0.0f, uvy = 0.0f;
+    unsigned meshIndex = 0u;
+    int normalMap = -1;
+    MaterialWords mw{s0, s0, s0, s0, s0};
+    v3 lookDir = rd;
+    if (isHit) {
+        // hit attributes of the winning triangle (intersection.glsl:41-57)
+        const float w = 1.0f - uHit - vHit;
+        P0 = ro + rd * tHit;
+        const float4* shp = reinterpret_cast<const float4*>(S.shading + prim);
+        s0 = shp[0], s1 = shp[1], s2 = shp[2], s3 = shp[3];
+        const float4 s4 = shp[4];
+        lookDir = sampleHdri(S, P.envW, P.envH, ps.rng);
+        uvx = s0.w * w + s2.w * uHit + s3.y * vHit;
+        uvy = s1.w * w + s3.x * uHit + s3.z * vHit;
+        N = normalize3(mk3(s0.x, s0.y, s0.z) * w + mk3(s1.x, s1.y, s1.z) * uHit + mk3(s2.x, s2.y, s2.z) * vHit);
+        Ng = mk3(s4.x, s4.y, s4.z);
+        meshIndex = __float_as_uint(s3.w);
+        mw = loadMaterial(S, meshIndex);
+        normalMap = S.materials[meshIndex].tex[kTexNormal];
+    }
     float pdfLight = 0.0f;
-    const v3 colorLight = evaluateHdri(S, P.envW, P.envH, P.hdriW, P.hdriH, Ll, pdfLight);
+    const v3 colorLight = evaluateHdri(S, P.envW, P.envH, P.hdriW, P.hdriH, lookDir, pdfLight);
+    if (!isHit) {
+        float misWeight = 1.0f;
+        if (ps.bounce > 0u) {
+            float t = ps.pdfBsdf * ps.pdfBsdf;
+            misWeight = t / (pdfLight * pdfLight + t);
+        }
+        if (misWeight > 0.0f) ps.radiance = ps.radiance + misWeight * ps.throughput * colorLight * ps.f / ps.pdfBsdf;
+        return out;
+    }
+    const v3 Ll = lookDir;
     v3 tangent = splat(0.0f);
     if (normalMap >= 0) {
         const float4* tp = reinterpret_cast<const float4*>(S.triangles + prim);
@@ -574,6 +601,16 @@ PT_DEV BounceRays shadeHit(const DevParams& P, const DevScene& S, PathState& ps,
         }
     }
     return out;
+}
+
+PT_DEV void shadeMiss(const DevParams& P, const DevScene& S, PathState& ps, v3 rd)
+{
+    (void)shadeRay(P, S, ps, rd, rd, -1, 0.0f, 0.0f, 0.0f, false);
+}
+PT_DEV BounceRays shadeHit(const DevParams& P, const DevScene& S, PathState& ps, v3 ro, v3 rd, int prim, float tHit,
+                           float uHit, float vHit)
+{
+    return shadeRay(P, S, ps, ro, rd, prim, tHit, uHit, vHit, true);
 }
 
 // Miss or hit in one call (prim < 0 is a miss), for callers that shade one ray per lane.
@@ -799,27 +836,27 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
             prof[7] += (unsigned)__popcll(__ballot(mode == kModeShade && q.bestPrim >= 0));
             prof[8] += (unsigned)__popcll(__ballot(mode == kModeShade && q.bestPrim < 0));
         }
-        // a miss ends the path: environment radiance, then FINISH
-        if (mode == kModeShade && q.bestPrim < 0) {
-            shadeMiss(P, S, ps, q.rd);
-            mode = kModeFinish;
-        }
-        if (COUNT) {
-            const unsigned long long now = __builtin_readcyclecounter();
-            prof[15] += now - tick;
-            prof[12] += now - tick;
-            tick = now;
-        }
-        // Hits are shaded once enough lanes hold one (the block is the most expensive of the phase
-        // and runs at the occupancy of the lanes that take part), or when too few other lanes
-        // are left to keep the traversal phase busy.
-        const int nHit = __popcll(__ballot(mode == kModeShade));
-        const int aliveNow = __popcll(__ballot(mode != kModeDone));
+        // A miss ends its path with the environment's radiance.  Hits are shaded once enough lanes hold one (the
+        // block is the most expensive of the phase and runs at the occupancy of the lanes that take part), or when too
+        // few other lanes are left to keep the traversal phase busy.  Misses and the hits that are due go through the
+        // shading code together: its environment lookup serves both.
+        const bool isMiss = mode == kModeShade && q.bestPrim < 0;
+        const int nHit = __popcll(__ballot(mode == kModeShade && q.bestPrim >= 0));
+        const int aliveNow = __popcll(__ballot(mode != kModeDone)) - __popcll(__ballot(isMiss));  // (a miss is on its way to FINISH)
         const bool doHit = nHit >= ((aliveNow * (int)P.hitMinNum + 63) >> 6) ||
                            aliveNow - nHit < ((aliveNow * (int)P.travExitNum + 63) >> 6);
-        if (doHit && mode == kModeShade) {
-            nHits++;
-            const BounceRays br = shadeHit(P, S, ps, q.ro, q.rd, q.bestPrim, q.bestT, q.bestU, q.bestV);
+        const bool isHit = doHit && mode == kModeShade && q.bestPrim >= 0;
+#ifdef PT_EXPERIMENT_COUNT_PHASES
+        if (COUNT) {
+            const bool anyMiss = __ballot(isMiss) != 0ull, anyHit = __ballot(isHit) != 0ull;
+            prof[15] += (anyMiss && anyHit) ? 1u : 0u;
+            prof[10] += anyHit ? 1u : 0u;   // (these two slots hold other tallies in a regular build)
+            prof[11] += anyMiss ? 1u : 0u;
+        }
+#endif
+        if (isMiss || isHit) {
+            const BounceRays br = shadeRay(P, S, ps, q.ro, q.rd, q.bestPrim, q.bestT, q.bestU, q.bestV, isHit);
+            nHits += isHit;
             mode = kModeFinish;
             hasExt = false;
             if (br.hasShadow) {

@@ -25,10 +25,11 @@
 
 namespace ptcore {
 
-#ifndef PT_LBVH_LEAF_MAX
-#define PT_LBVH_LEAF_MAX 4
-#endif
-constexpr int kLbvhLeafMax = PT_LBVH_LEAF_MAX;  // BVH::BuildBvhWithSah is called with leaf size 4 (PathTracingRenderer.cpp:583)
+// Most triangles a leaf of the device-built tree may hold (LbvhTree::leafMax, PlocNodes::leafMax), chosen per build:
+// 2 for scenes the caches hold (the triangle half of the traversal step runs at a third of the lanes: a cheap box more and
+// a triangle test fewer is 2-4 % faster on every such scene measured), the reference's 4 (BVH::BuildBvhWithSah is called
+// with leaf size 4, PathTracingRenderer.cpp:583) for scenes that stream from HBM, where the extra nodes cost more.
+constexpr int kLbvhLeafLimit = 4;
 
 struct LbvhBounds {
     unsigned int lo[3], hi[3];  // order-preserving encodings of floats
@@ -144,6 +145,7 @@ struct LbvhTree {
     float* box;       // (2n-1) x 6: min xyz, max xyz
     int* height;      // n-1: interior levels below and including the node
     unsigned int* visits;  // n-1 arrival counters of the fit pass
+    int leafMax;      // sub-trees of at most this many triangles become leaves
 };
 
 __global__ void lbvhTreeKernel(const unsigned long long* __restrict__ keys, int n, LbvhTree T)
@@ -224,12 +226,12 @@ __global__ void lbvhCountKernel(int n, LbvhTree T, unsigned int* emit, unsigned 
 {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n - 1) return;
-    const bool keep = lbvhCount(T, n, i) > kLbvhLeafMax;
+    const bool keep = lbvhCount(T, n, i) > T.leafMax;
     unsigned int e = 0;
     if (keep) {
         e = 1u;
-        if (lbvhCount(T, n, T.left[i]) <= kLbvhLeafMax) e++;
-        if (lbvhCount(T, n, T.right[i]) <= kLbvhLeafMax) e++;
+        if (lbvhCount(T, n, T.left[i]) <= T.leafMax) e++;
+        if (lbvhCount(T, n, T.right[i]) <= T.leafMax) e++;
     }
     emit[i] = e;
     kept[i] = keep ? 1u : 0u;
@@ -265,7 +267,7 @@ __global__ void lbvhEmitNodesKernel(int n, LbvhTree T, const unsigned int* __res
     for (int c = 0; c < 2; c++) {
         const int u = child[c];
         const int count = lbvhCount(T, n, u);
-        if (count <= kLbvhLeafMax) {
+        if (count <= T.leafMax) {
             const int first = lbvhFirst(T, n, u);
             refId[c] = nextLeaf;
             lbvhWriteRefNode(refNodes + nextLeaf, 0, 0, count, first, T.box + (size_t)u * 6);
@@ -341,7 +343,7 @@ __global__ void lbvhEmitTrianglesKernel(const RefPrimitiveAlign* __restrict__ pr
     shading[k] = s;
 }
 
-// A scene of at most kLbvhLeafMax triangles: the root is a leaf (reference node 1).
+// A scene of at most leafMax triangles: the root is a leaf (reference node 1).
 __global__ void lbvhEmitRootLeafKernel(int n, LbvhTree T, RefNodeAlign* refNodes, DevNode* devNodes)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;

@@ -22,8 +22,9 @@ struct PlocNodes {
     int* height;    // n-1: interior levels below and including the node
     float* box;     // (2n-1) x 6
     int* position;  // 2n-1: first position of the node's triangles in the final order
-    int* kept;      // 2n-1: nodes of the sub-tree that stay interior nodes (more than kLbvhLeafMax triangles)
+    int* kept;      // 2n-1: nodes of the sub-tree that stay interior nodes (more than leafMax triangles)
     int* preorder;  // 2n-1: rank of the node among the kept nodes in depth-first order, left before right
+    int leafMax;    // sub-trees of at most this many triangles become leaves
 };
 
 __device__ __forceinline__ float plocArea(const float* a, const float* b)
@@ -115,7 +116,7 @@ __global__ void plocMergeKernel(const int* __restrict__ idIn, const float* __res
         N.right[k] = o;
         const int size = N.size[a] + N.size[o];
         N.size[id] = size;
-        N.kept[id] = (size > kLbvhLeafMax ? 1 : 0) + N.kept[a] + N.kept[o];
+        N.kept[id] = (size > N.leafMax ? 1 : 0) + N.kept[a] + N.kept[o];
         const int ha = a < n ? 0 : N.height[a - n], ho = o < n ? 0 : N.height[o - n];
         N.height[k] = 1 + (ha > ho ? ha : ho);
         for (int c = 0; c < 6; c++) N.box[(size_t)id * 6 + c] = b[c];

@@ -41,7 +41,7 @@ g.upload_environment(work["hdri"], work["cache"])
 p = R.default_params(a.width, a.height)
 p.max_bounces = a.bounces
 g.set_params(p)
-defaults = dict(pipeline=0, trav_exit=32, refill_min=16, check_every=2, traverse_blocks=0, hit_min=16, tile_order=1, tile_split=-1, sample_budget_mib=8192, pull_items=1)
+defaults = dict(pipeline=0, trav_exit=28, refill_min=16, check_every=2, traverse_blocks=0, hit_min=28, tile_order=1, tile_split=-1, sample_budget_mib=8192, pull_items=1)
 variants = []
 for v in a.variants:
     kw = dict(defaults)
