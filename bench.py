@@ -41,17 +41,22 @@ MALL_GATHER_GBS = 8600.0  # measured ceiling for random rows served by the Infin
 # The reference's Dragon.glb is missing; the Stanford dragon it is commonly built from has ~871 k
 # triangles.  The bunny (144 k) subdivided once (576 k) is the closest stand-in at hand.
 DEFAULT_SUBDIVIDE = 1
-# Canonical record sizes for algorithmic bytes per ray: one four-wide node (4 AABBs + 4 refs),
-# one triangle (3 vertices padded), shading record, material record; one 36-byte record
+# Record sizes for algorithmic bytes per ray, as the kernels read them: one four-wide node (4 quantised AABBs
+# + 4 refs: 64 B), one triangle (3 vertices padded), shading record, material record; one 36-byte record
 # (radiance, albedo, normal: three floats each) per finished sample; 96 B of image traffic (three
-# RGBA32F texels read + written) per pixel and launch.
-S_NODE, S_TRI, S_SHADE, S_MAT, S_SAMPLE, S_ACC = 128, 48, 64, 80, 36, 96
+# RGBA32F texels read + written) per pixel and launch.  S_NODE_EXACT: the same node with exact float boxes
+# (two of the two-child 64-byte nodes the byte model was first stated with; what rounds 1-2 counted).
+S_NODE, S_TRI, S_SHADE, S_MAT, S_SAMPLE, S_ACC = 64, 48, 64, 80, 36, 96
+S_NODE_EXACT = 128
 
 SCENES = {  # name -> (metric label, default width, height, bounces)
     "dragonglass": ("1080p DragonGlass", 1920, 1080, 8),
     "interior": ("1080p interior (Fireplace stand-in)", 1920, 1080, 8),
     "spheres": ("1080p sphere field", 1920, 1080, 16),
     "c1": ("512x512 BunnyClearcoat", 512, 512, 3),
+    # the headline scene from 0.85 units in front of the glass mesh, which then fills the frame (the reference camera sees
+    # mostly floor and sky): most rays start inside the mesh's boxes
+    "closeup": ("1080p DragonGlass, close-up", 1920, 1080, 8),
 }
 
 
@@ -75,6 +80,8 @@ def build_workload(args):
         meshes, mats, side = scenes.instanced_bunnies(copies)
     else:
         meshes, mats = scenes.flatten(scenes.recipe("DragonGlass"))
+        if scene == "closeup":
+            camera = dict(eye=(-0.15, 0.8, 0.85), look_at=(-0.15, 0.8, 0.0))
     subdivide = getattr(args, "subdivide", 0) or 0
     if subdivide > 0:
         v, i = meshes[0]
@@ -263,7 +270,7 @@ def main():
     H = args.height or dh
     args.bounces = args.bounces or db
     if args.subdivide is None:
-        args.subdivide = DEFAULT_SUBDIVIDE if (args.scene == "dragonglass" and args.copies == 1) else 0
+        args.subdivide = DEFAULT_SUBDIVIDE if (args.scene in ("dragonglass", "closeup") and args.copies == 1) else 0
     S = args.spp_per_step
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -335,6 +342,7 @@ def main():
     st = g.stats()
     rays_step = st.rays_closest + st.rays_any
     bytes_per_ray = (st.node_visits * S_NODE + st.triangle_tests * S_TRI + st.closest_hits * (S_SHADE + S_MAT)) / rays_step
+    bytes_per_ray_exact_nodes = bytes_per_ray + st.node_visits * (S_NODE_EXACT - S_NODE) / rays_step
     # the trace kernel writes one 36-byte record per finished sample; the resolve kernel reads the
     # records back and updates the three images once per launch (16 B read + 16 B written each)
     bytes_per_launch = bytes_per_ray * rays_step + st.samples * S_SAMPLE
@@ -399,8 +407,9 @@ def main():
         if args.copies > 1:
             what = f"DragonGlass recipe on {args.copies} flattened bunnies + floor ({work['triangles']} triangles), "
             label = f"{W}x{H} DragonGlass on {work['triangles'] / 1e6:.0f} M triangles"
-        elif args.scene == "dragonglass":
-            what = f"DragonGlass recipe on bunny.glb (subdivided x{args.subdivide}) + Floor.glb stand-in ({work['triangles']} triangles), "
+        elif args.scene in ("dragonglass", "closeup"):
+            what = (f"DragonGlass recipe on bunny.glb (subdivided x{args.subdivide}) + Floor.glb stand-in ({work['triangles']} triangles), " +
+                    ("camera 0.85 units in front of the mesh (it fills the frame), " if args.scene == "closeup" else ""))
         elif args.scene == "interior":
             what = (f"interior stand-in for the Fireplace scene: closed textured room with one window, AreaLight and Mill content "
                     f"({work['triangles']} triangles), ")
@@ -452,7 +461,8 @@ def main():
                 # `achieved` = ALGORITHMIC bytes per launch over the trace kernel's HIP-event time, measured in this run.
                 # `peak` / `frac` rate them against the memory level that serves them: the eight L2s for a scene the
                 # caches hold, HBM for one they cannot; `frac_hbm` is the same figure against the HBM peak.
-                "bound": (pmc.get("bound") if pmc and pmc.get("bound") else ("hbm" if not cache_resident else "l1-gather")),
+                "bound": "hbm",  # a memory-system roofline: the path has no dense contraction, no MFMA
+                "limited_by": pmc.get("limited_by") if pmc else None,
                 "achieved": achieved,
                 "peak": L2_PEAK_GBS if cache_resident else HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -464,10 +474,10 @@ def main():
                 "note": ("measured in this run: achieved, frac, frac_hbm, kernel_ms_avg, the per-ray counts, resolve_kernel, ms_per_step_*. "
                          "Read from pmc_source (rocprofv3 counter passes of the same command on the same launch shape, not this run): "
                          "traffic, fabric_gbps, fabric_frac, l1_busy, l1_stall, valu_pipe_share, valu_busy, lane_utilisation, "
-                         "waves_per_simd, l2_hit, bound. achieved counts ALGORITHMIC bytes: on a cache-resident scene the vector L1s "
+                         "waves_per_simd, l2_hit, limited_by. achieved counts ALGORITHMIC bytes: on a cache-resident scene the vector L1s "
                          "and the L2s serve them, so frac_hbm can exceed 1 and peak is the L2s' measured aggregate; traffic / "
-                         "fabric_gbps are the bytes leaving the L2s; l1_busy + l1_stall (share of the CUs' cycles in which the vector "
-                         "L1 takes an access, one per cycle, or is held up by misses in flight) say what bounds the kernel"),
+                         "fabric_gbps are the bytes leaving the L2s; l1_busy / l1_stall: share of the CUs' cycles in which the vector "
+                         "L1 takes an access, one per cycle, or is held up by misses in flight (the two always add up to 1)"),
                 "frac_l2": achieved / L2_PEAK_GBS,
                 "fabric_gbps": (traffic / avg_kernel_s / 1e9) if traffic else None,
                 "fabric_frac": ((traffic / avg_kernel_s / 1e9) / (MALL_GATHER_GBS if cache_resident else HBM_PEAK_GBS)) if traffic else None,
@@ -483,6 +493,7 @@ def main():
                 "kernel": "renderKernel" if avg_resolve_s > 0 else "traverseKernel + shadeKernel (whole dispatch)",
                 "kernel_ms_avg": avg_kernel_s * 1e3,
                 "algorithmic_bytes_per_ray": bytes_per_ray,
+                "bytes_per_ray_with_exact_128B_nodes": bytes_per_ray_exact_nodes,  # the earlier rounds' accounting, for comparison
                 "rays_per_launch": rays_step,
                 "node_visits_per_ray": st.node_visits / rays_step,
                 "triangle_tests_per_ray": st.triangle_tests / rays_step,

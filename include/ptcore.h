@@ -139,7 +139,9 @@ int pt_upload_primitives(pt_ctx* ctx, const void* prims112, size_t count);
  * split cost and cuts the top of any sizeable scene at the median along X, which costs 1.1-4x the node
  * visits per ray; a host that keeps calling it gets the better tree with no change on its side, and the
  * same images (the tree only decides where rays look; equal except where two hit distances tie exactly).
- * enable = 0: the uploaded tree itself is folded and traversed.  pt_download_bvh returns the tree in use. */
+ * enable = 0: the uploaded tree itself is folded and traversed.  pt_download_bvh returns the tree in use.
+ * A tree made by pt_process_buffers / pt_process_buffers_full_sweep is always traversed as built: there the
+ * caller has named its builder (pt_process_buffers_device is the call that names the GPU builder). */
 int pt_set_bvh_rebuild(pt_ctx* ctx, int enable);
 /* SSBO binding 1 (PathTracingRenderer.cpp:509-564): MaterialAlign records of 176 B.  The 11
  * 64-bit bindless handles are reinterpreted as 1-based slots of pt_upload_texture

@@ -840,12 +840,21 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
         // block is the most expensive of the phase and runs at the occupancy of the lanes that take part), or when too
         // few other lanes are left to keep the traversal phase busy.  Misses and the hits that are due go through the
         // shading code together: its environment lookup serves both.
+#ifdef PT_EXPERIMENT_MISSES_WAIT  // misses wait for the shading block like hits: both kinds count towards its threshold
+        const int nShade = __popcll(__ballot(mode == kModeShade));
+        const int aliveNow = __popcll(__ballot(mode != kModeDone));
+        const bool doHit = nShade >= ((aliveNow * (int)P.hitMinNum + 63) >> 6) ||
+                           aliveNow - nShade < ((aliveNow * (int)P.travExitNum + 63) >> 6);
+        const bool isMiss = doHit && mode == kModeShade && q.bestPrim < 0;
+        const bool isHit = doHit && mode == kModeShade && q.bestPrim >= 0;
+#else
         const bool isMiss = mode == kModeShade && q.bestPrim < 0;
         const int nHit = __popcll(__ballot(mode == kModeShade && q.bestPrim >= 0));
         const int aliveNow = __popcll(__ballot(mode != kModeDone)) - __popcll(__ballot(isMiss));  // (a miss is on its way to FINISH)
         const bool doHit = nHit >= ((aliveNow * (int)P.hitMinNum + 63) >> 6) ||
                            aliveNow - nHit < ((aliveNow * (int)P.travExitNum + 63) >> 6);
         const bool isHit = doHit && mode == kModeShade && q.bestPrim >= 0;
+#endif
 #ifdef PT_EXPERIMENT_COUNT_PHASES
         if (COUNT) {
             const bool anyMiss = __ballot(isMiss) != 0ull, anyHit = __ballot(isHit) != 0ull;

@@ -162,6 +162,7 @@ struct pt_ctx {
     uint64_t sampleBudgetBytes = 8ull << 30;
     int wavesPerSimd = 0;      // megakernel variant: 3 or 4 waves per SIMD (0: the default, 3)
     bool rebuildOnUpload = true;  // pt_upload_nodes' tree is checked, then replaced by the device builder's over the same primitives
+    bool builderChosen = false;   // the tree on record comes from pt_process_buffers / _full_sweep: the caller named its builder, it stays
     int bvhLeafMax = 0;   // device BVH builder: most triangles per leaf (0: by scene size)
     int plocRadius = 32;  // device BVH builder: neighbours searched on either side per clustering round (0: Morton radix tree)
     bool pullItems = true;  // megakernel: resident waves pull the work items (else one block per item)
@@ -287,7 +288,7 @@ int syncScene(pt_ctx* c)
         std::string err = PackScene(c->nodes.data(), c->nodes.size(), c->prims.data(), c->prims.size(),
                                     c->materials.size(), packed);
         if (!err.empty()) return fail(PT_ERR_SCENE, err);
-        if (c->rebuildOnUpload) {
+        if (c->rebuildOnUpload && !c->builderChosen) {
             // the uploaded tree was only validated; the device builder's tree over the same primitives is used
             std::vector<RefPrimitiveAlign> prims;
             std::vector<RefNodeAlign> nodes;
@@ -899,6 +900,7 @@ int pt_upload_nodes(pt_ctx* c, const void* nodes48, size_t count)
     c->nodes.assign(p, p + count);
     c->geometryDirty = true;
     c->deviceGeometry = false;
+    c->builderChosen = false;
     forgetTileCosts(c);
     return PT_OK;
 }
@@ -1047,6 +1049,7 @@ int processBuffers(pt_ctx* c, bool uncapped)
     rc = pt_upload_nodes(c, nodesAligned.data(), nodesAligned.size());
     if (rc != PT_OK) return rc;
     rc = pt_upload_primitives(c, primsAligned.data(), primsAligned.size());
+    if (rc == PT_OK) c->builderChosen = true;  // (pt_upload_nodes cleared it)
     return rc;
 }
 

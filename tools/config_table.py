@@ -33,16 +33,22 @@ def run(name, width, height, bounces, meshes, mats, textures=(), eye=None, look_
     g = R.Renderer(width, height)
     if args.tuning:  # before the scene goes in: some settings steer the device BVH builder
         g.set_tuning(**{k: int(v) for k, v in (item.split("=") for item in args.tuning.split(","))})
-    if args.no_rebuild:
-        g.set_bvh_rebuild(False)
     for slot, texels, srgb in textures:
         g.upload_texture(slot, texels, srgb)
-    for (v, i), m in zip(meshes, mats):
-        g.AddPathTracingModel(v, i, m)
-    if args.bvh == "device":
-        g.ProcessBuffersDevice()
+    if args.bvh == "device" or args.no_rebuild:
+        for (v, i), m in zip(meshes, mats):
+            g.AddPathTracingModel(v, i, m)
+        if args.bvh == "device":
+            g.ProcessBuffersDevice()
+        else:
+            g.ProcessBuffers(full_sweep=args.bvh == "full-sweep")  # (a tree of a builder named by the caller is traversed as built)
     else:
-        g.ProcessBuffers(full_sweep=args.bvh == "full-sweep")
+        # what the reference's host does: its own builder's tree, uploaded (the library then builds its own: the default)
+        soup = np.concatenate([R.assemble_primitives(v, i, k) for k, (v, i) in enumerate(meshes)])
+        sorted_prims, nodes40 = R.build_bvh_sah(soup, 4, full_sweep=args.bvh == "full-sweep")
+        g.upload_nodes(R.align_nodes(nodes40))
+        g.upload_primitives(R.align_primitives(sorted_prims))
+        g.upload_materials(np.array(list(mats), dtype=scenes.MATERIAL_DTYPE))
     g.upload_environment(hdri, cache)
     p = R.default_params(width, height)
     p.max_bounces = bounces

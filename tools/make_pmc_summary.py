@@ -57,10 +57,14 @@ def main(src, dst, shape):
         "valu_insts": c["SQ_INSTS_VALU"], "salu_insts": c["SQ_INSTS_SALU"], "vmem_rd_insts": c["SQ_INSTS_VMEM_RD"],
         "launch_info": k.get("launch_info"),
     })
-    vb = out["valu_busy"] or 0.0
-    l1 = (out["l1_busy"] or 0.0) + (out["l1_stall"] or 0.0)
-    out["bound"] = ("l1-gather" if l1 >= 0.9 and (out["l1_busy"] or 0.0) >= 0.5 else
-                    "valu-issue" if vb >= 0.6 else ("hbm" if traffic / (k["avg_ns"] / 1e9) / 1e9 > 4000.0 else "latency"))
+    # What limits the kernel.  (l1_busy + l1_stall is 1 whatever the kernel does -- stall cycles fill the cycles without an
+    # access -- so the pair says nothing about the bound; probes with extra instructions and extra reads per node visit
+    # show both the vector pipe and the L1 with slack: profiles/r03_bound_experiment.txt.)  A launch that moves more than
+    # half of the HBM peak through the fabric is called memory bound; otherwise a wave's serial chain of one memory round
+    # trip and a few hundred vector instructions per traversal step, with the two other waves of its SIMD to cover it.
+    out["bound"] = "hbm"
+    out["limited_by"] = ("fabric / HBM bandwidth" if traffic / (k["avg_ns"] / 1e9) / 1e9 > 4000.0 else
+                         "latency and issue at 3 waves per SIMD (registers and LDS cap the occupancy)")
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
