@@ -224,7 +224,7 @@ def pmc_summary(args, W, H, S):
     """Counter-derived figures of the trace kernel from the committed rocprofv3 PMC summary, valid
     only for the launch shape they were collected on."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")), reverse=True):  # (a later round's first)
         try:
             t = json.load(open(path))
         except Exception:
