@@ -775,3 +775,67 @@ def test_traversal_stack_beyond_32_entries(pipeline):
         assert images["chain"][k].tobytes() == images["chain-pull"][k].tobytes()
         assert images["chain"][k].tobytes() == images["sah"][k].tobytes()
     assert np.any(images["chain"][0][..., :3] > 0)
+
+
+def _transformed_scene(recipe, scale, offset):
+    """The recipe's meshes scaled and moved (positions only), the reference builder's tree over them."""
+    from tests.common import built_meshes
+    meshes, mats = scenes.flatten(scenes.recipe(recipe))
+    moved = []
+    for v, i in meshes:
+        v = v.copy()
+        v[:, 0:3] = v[:, 0:3] * np.float32(scale) + np.asarray(offset, np.float32)
+        moved.append((v, i))
+    return built_meshes(moved, mats)
+
+
+@pytest.mark.parametrize("rebuild", [True, False], ids=["library-tree", "uploaded-tree"])
+@pytest.mark.parametrize("scale,offset", [(1.0, (1000.0, 0.0, -2000.0)), (0.1, (0.0, 0.0, 0.0)), (500.0, (3.0e4, 0.0, 0.0))],
+                         ids=["far-from-origin", "tenth-scale", "large-and-far"])
+def test_grid_boxes_hold_far_from_the_origin_and_at_other_scales(scale, offset, rebuild):
+    """The traversal's boxes are grid planes around the exact ones, and its slab distances are multiply-adds in
+    the node's grid; both lose precision where coordinates are large against the node (a scene far from the
+    origin) and where cells get tiny.  The images must still be the oracle's, bit for bit: a box test that
+    wrongly missed would drop a hit."""
+    scene = _transformed_scene("TorusMixed", scale, offset)
+    w, h = 128, 96
+    o, g = _pair(scene, w, h)
+    g.set_bvh_rebuild(rebuild)
+    p = R.default_params(w, h)
+    p.max_bounces = 4
+    eye = tuple(np.float32(c) * np.float32(scale) + np.float32(d) for c, d in zip((-2.5, 1.0, 0.3), offset))
+    R.set_camera(p, eye, tuple(float(x) for x in offset), w, h)
+    g.set_params(p)
+    g.clear()
+    g.dispatch(1, 3, 1, counted=True)
+    gpu = [g.read_image(k) for k in range(3)]
+    cpu = o.render(p, w, h, 1, 3, 1)
+    _assert_images_equal(gpu, cpu[:3], cpu[3], f"TorusMixed x{scale} at {offset}")
+    st = g.stats()
+    assert st.closest_hits == cpu[4].closest_hits and st.closest_hits > 0.2 * w * h
+
+
+def test_axis_parallel_rays_through_grid_boxes():
+    """Rays with direction components of exactly zero (an axis-aligned camera, no anti-aliasing, odd image size:
+    the centre row and column) take the clamped-reciprocal path of the box test, where the shader has
+    infinities; boxes of an axis-aligned cube and floor have zero extent on an axis at some nodes."""
+    from tests.common import built_meshes
+    cube_v, cube_i = scenes.load_ptm("cube")
+    floor_v, floor_i = scenes.load_ptm("floor")
+    mats = np.array([scenes.material(albedo=(0.8, 0.3, 0.2), roughness=0.4, metallic=0.3), scenes.floor_material()],
+                    dtype=scenes.MATERIAL_DTYPE)
+    scene = built_meshes([(cube_v, cube_i), (floor_v, floor_i)], mats)
+    w, h = 65, 49
+    for rebuild in (True, False):
+        o, g = _pair(scene, w, h)
+        g.set_bvh_rebuild(rebuild)
+        p = R.default_params(w, h)
+        p.anti_aliasing_enabled = 0
+        R.set_camera(p, (0.0, 0.5, 6.0), (0.0, 0.5, 0.0), w, h)  # looking straight down -z
+        g.set_params(p)
+        g.clear()
+        g.dispatch(1, 2, 1)
+        gpu = [g.read_image(k) for k in range(3)]
+        cpu = o.render(p, w, h, 1, 2, 1)
+        _assert_images_equal(gpu, cpu[:3], cpu[3], f"axis-aligned camera, rebuild={rebuild}")
+        assert np.any(gpu[1][h // 2, w // 2, :3] > 0)  # the centre ray hits the cube
