@@ -474,7 +474,7 @@ def main():
                 "note": ("measured in this run: achieved, frac, frac_hbm, kernel_ms_avg, the per-ray counts, resolve_kernel, ms_per_step_*. "
                          "Read from pmc_source (rocprofv3 counter passes of the same command on the same launch shape, not this run): "
                          "traffic, fabric_gbps, fabric_frac, l1_busy, l1_stall, valu_pipe_share, valu_busy, lane_utilisation, "
-                         "waves_per_simd, l2_hit, limited_by. achieved counts ALGORITHMIC bytes: on a cache-resident scene the vector L1s "
+                         "waves_per_simd, l2_hit, l2_request_gbps, l1_l2_read_latency_cycles, limited_by. achieved counts ALGORITHMIC bytes: on a cache-resident scene the vector L1s "
                          "and the L2s serve them, so frac_hbm can exceed 1 and peak is the L2s' measured aggregate; traffic / "
                          "fabric_gbps are the bytes leaving the L2s; l1_busy / l1_stall: share of the CUs' cycles in which the vector "
                          "L1 takes an access, one per cycle, or is held up by misses in flight (the two always add up to 1)"),
@@ -489,6 +489,8 @@ def main():
                 "lane_utilisation": pmc.get("lane_utilisation") if pmc else None,
                 "waves_per_simd": pmc.get("waves_per_simd") if pmc else None,
                 "l2_hit": pmc.get("l2_hit") if pmc else None,
+                "l2_request_gbps": pmc.get("l2_request_gbps") if pmc else None,  # L2 requests x 128-byte line / kernel time
+                "l1_l2_read_latency_cycles": pmc.get("l1_l2_read_latency_cycles") if pmc else None,
                 "pmc_source": pmc.get("source") if pmc else None,
                 "kernel": "renderKernel" if avg_resolve_s > 0 else "traverseKernel + shadeKernel (whole dispatch)",
                 "kernel_ms_avg": avg_kernel_s * 1e3,

@@ -46,6 +46,16 @@ struct Bounds {
 inline float gmin(float a, float b) { return (b < a) ? b : a; }
 inline float gmax(float a, float b) { return (a < b) ? b : a; }
 
+// Surface area of `b` times `count`, every operation in binary32 and in this order.
+inline float surfaceTimesCount(const Bounds& b, int count)
+{
+    const float ex = b.hi[0] - b.lo[0];
+    const float ey = b.hi[1] - b.lo[1];
+    const float ez = b.hi[2] - b.lo[2];
+    const float area = 2.0f * ((ex * ey) + (ex * ez) + (ey * ez));
+    return area * (float)count;
+}
+
 struct Builder {
     const std::vector<Bounds>& bounds;  // per original primitive id
     std::vector<Key>& keys;             // current order
@@ -119,22 +129,13 @@ struct Builder {
                     run.hi[k] = gmax(run.hi[k], b.hi[k]);
                     run.lo[k] = gmin(run.lo[k], b.lo[k]);
                 }
-                float lenx = run.hi[0] - run.lo[0];
-                float leny = run.hi[1] - run.lo[1];
-                float lenz = run.hi[2] - run.lo[2];
-                float leftS = 2.0f * ((lenx * leny) + (lenx * lenz) + (leny * lenz));
-                float leftCost = leftS * (float)(i - l + 1);
-
-                const Bounds& rb = suffix[i + 1 - l];
-                lenx = rb.hi[0] - rb.lo[0];
-                leny = rb.hi[1] - rb.lo[1];
-                lenz = rb.hi[2] - rb.lo[2];
-                float rightS = 2.0f * ((lenx * leny) + (lenx * lenz) + (leny * lenz));
-                float rightCost = rightS * (float)(r - i);
-
-                float totalCost = leftCost + rightCost;
-                if (totalCost < cost) {
-                    cost = totalCost;
+                // surface area x triangle count on either side of the cut, in the reference's order of
+                // operations (BVH.cpp:187-213: extents, 2 * (xy + xz + yz), times the count, summed)
+                const float sideL = surfaceTimesCount(run, i - l + 1);
+                const float sideR = surfaceTimesCount(suffix[i + 1 - l], r - i);
+                const float both = sideL + sideR;
+                if (both < cost) {
+                    cost = both;
                     split = i;
                 }
             }

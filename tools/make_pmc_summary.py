@@ -54,6 +54,12 @@ def main(src, dst, shape):
         "waves_per_simd": 4.0 * c["SQ_WAVE_CYCLES"] / (busy * SIMDS),
         "wave_wait_share": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
         "l2_hit": c["TCC_HIT_sum"] / max(c["TCC_REQ_sum"], 1.0),
+        # what the L2s were asked for: requests x the 128-byte line (an upper estimate, a request moves at most one
+        # line), and how long a vector L1 waited for a line it asked the L2 for, on average, in L1 clock cycles
+        "l2_requests": c["TCC_REQ_sum"],
+        "l2_request_gbps": c["TCC_REQ_sum"] * 128.0 / (k["avg_ns"] / 1e9) / 1e9,
+        "l1_l2_read_latency_cycles": (c["TCP_TCC_READ_REQ_LATENCY_sum"] / max(c["TCP_TCC_READ_REQ_sum"], 1.0)
+                                      if "TCP_TCC_READ_REQ_LATENCY_sum" in c else None),
         "valu_insts": c["SQ_INSTS_VALU"], "salu_insts": c["SQ_INSTS_SALU"], "vmem_rd_insts": c["SQ_INSTS_VMEM_RD"],
         "launch_info": k.get("launch_info"),
     })
