@@ -151,7 +151,8 @@ int pt_upload_materials(pt_ctx* ctx, const void* mats176, size_t count);
  * PathTracingRenderPass.cpp:47-50).  slot >= 1.  channels 1..4; texels are u8 (unorm,
  * is_srgb decodes the colour channels like GL_SRGB8) or f32 when is_float.  Row 0 is the
  * GL row 0 (the caller applies the loader's vertical flip).  Sampling is bilinear, REPEAT,
- * base level. */
+ * base level; a texture of fewer than four channels reads as (r, 0, 0, 1) / (r, g, 0, 1) / (r, g, b, 1).
+ * On the device every texel takes four channels; all textures together must stay below 4 GB in that form. */
 int pt_upload_texture(pt_ctx* ctx, int slot, int width, int height, int channels, int is_srgb, int is_float,
                       const void* texels);
 /* SSBO binding 0 + the two environment textures (PathTracingRenderer.cpp:463-507): RGB32F
@@ -366,7 +367,10 @@ int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, 
  * of consecutive pt_dispatch calls may overlap, the next call's waves filling the chip while the last waves of
  * the call before run dry (1), never do (0), or do for calls of at most 8 frames (-1, the default); calls
  * overlap on the library's own stream only, never on one set with pt_set_stream; 13: device BVH builder: most
- * triangles per leaf, 1..4 (default 0: 2 for scenes of up to 1.3 M triangles, which the caches hold, 4 above). */
+ * triangles per leaf, 1..4 (default 0: 2 for scenes of up to 1.3 M triangles, which the caches hold, 4 above);
+ * 14: 8-bit textures are kept on the device as decoded floats (four per texel: a bilinear tap is one 16-byte read) while
+ * all of them together fit in this many MiB, and as 8-bit words with a decode table beyond (default 256; 0 = never
+ * decode).  Either form gives the same bits. */
 int pt_debug_set_tuning(pt_ctx* ctx, int key, int value);
 
 /* Profiling hook, not part of the drop-in surface (no counterpart in the reference): wave-level

@@ -164,6 +164,7 @@ struct pt_ctx {
     bool rebuildOnUpload = true;  // pt_upload_nodes' tree is checked, then replaced by the device builder's over the same primitives
     bool builderChosen = false;   // the tree on record comes from pt_process_buffers / _full_sweep: the caller named its builder, it stays
     int bvhLeafMax = 0;   // device BVH builder: most triangles per leaf (0: by scene size)
+    size_t textureDecodeBytes = 256u << 20;  // 8-bit textures are kept as decoded floats while they fit in this many bytes in all (the Infinity Cache's size)
     int plocRadius = 32;  // device BVH builder: neighbours searched on either side per clustering round (0: Morton radix tree)
     bool pullItems = true;  // megakernel: resident waves pull the work items (else one block per item)
     size_t waveTimeCount = 0;
@@ -329,6 +330,23 @@ int syncScene(pt_ctx* c)
     if (c->texturesDirty) {
         std::vector<DevTexture> table;
         std::vector<unsigned char> arena;
+        // 8-bit channel -> float: entries 0..255 unsigned-normalised (b / 255, one correctly rounded binary32
+        // division), entries 256..511 the GL_SRGB8 decode
+        float lut[512];
+        for (int i = 0; i < 256; i++) {
+            lut[i] = (float)i / 255.0f;
+            double sd = i / 255.0;
+            lut[256 + i] = (float)(sd <= 0.04045 ? sd / 12.92 : std::pow((sd + 0.055) / 1.055, 2.4));
+        }
+        // Every texel goes into the arena with four channels -- (r, 0, 0, 1), (r, g, 0, 1), (r, g, b, 1) for
+        // textures of fewer, which is what a sampler returns for them -- so that a tap is ONE read.  8-bit textures
+        // are decoded here, once, into four floats a texel (the table above; alpha is never sRGB) as long as all of
+        // them together stay within `textureDecodeBytes`: a tap is then 16 bytes and needs no table lookups behind it.
+        // Beyond that they stay 8-bit, a tap is a 32-bit word and the kernels look the four channels up in the table.
+        size_t decoded = 0;
+        for (const HostTexture& t : c->textures)
+            if (t.present && t.format != 2) decoded += (size_t)t.width * (size_t)t.height * 16;
+        const bool decode = decoded <= c->textureDecodeBytes;
         for (const HostTexture& t : c->textures) {
             if (!t.present) continue;
             DevTexture d{};
@@ -337,15 +355,36 @@ int syncScene(pt_ctx* c)
             d.width = t.width;
             d.height = t.height;
             d.channels = t.channels;
-            d.format = t.format;
-            arena.insert(arena.end(), t.bytes.begin(), t.bytes.end());
+            d.format = (t.format != 2 && decode) ? 2 : t.format;
+            const size_t texels = (size_t)t.width * (size_t)t.height;
+            const size_t at = arena.size();
+            if (t.format == 2 || decode) {
+                arena.resize(at + texels * 16);
+                float* o = reinterpret_cast<float*>(arena.data() + at);
+                const float* sf = reinterpret_cast<const float*>(t.bytes.data());
+                const unsigned char* sb = t.bytes.data();
+                const float* colour = lut + (t.format == 1 ? 256 : 0);
+                for (size_t i = 0; i < texels; i++)
+                    for (int ch = 0; ch < 4; ch++) {
+                        float v = ch == 3 ? 1.0f : 0.0f;
+                        if (ch < t.channels) {
+                            const size_t k = i * (size_t)t.channels + (size_t)ch;
+                            v = t.format == 2 ? sf[k] : (ch == 3 ? lut[sb[k]] : colour[sb[k]]);
+                        }
+                        o[i * 4 + (size_t)ch] = v;
+                    }
+            } else {
+                arena.resize(at + texels * 4);
+                unsigned char* o = arena.data() + at;
+                const unsigned char* sb = t.bytes.data();
+                for (size_t i = 0; i < texels; i++)
+                    for (int ch = 0; ch < 4; ch++)
+                        o[i * 4 + (size_t)ch] = ch < t.channels ? sb[i * (size_t)t.channels + (size_t)ch] : (ch == 3 ? 255 : 0);
+            }
             table.push_back(d);
         }
-        float lut[256];
-        for (int i = 0; i < 256; i++) {  // GL_SRGB8 decode
-            double s = i / 255.0;
-            lut[i] = (float)(s <= 0.04045 ? s / 12.92 : std::pow((s + 0.055) / 1.055, 2.4));
-        }
+        if (arena.size() >= (1ull << 32))
+            return fail(PT_ERR_SCENE, "textures of 4 GB or more in all (four channels a texel; the kernels address texels by 32-bit byte offsets)");
         HIP_TRY(c->dTextures.ensure(table.size() * sizeof(DevTexture)));
         HIP_TRY(c->dTexels.ensure(arena.size()));
         HIP_TRY(c->dSrgbLut.ensure(sizeof(lut)));
@@ -1557,6 +1596,11 @@ int pt_debug_set_tuning(pt_ctx* c, int key, int value)
     case 13:
         if (value < 0 || value > kLbvhLeafLimit) return fail(PT_ERR_INVALID, "triangles per leaf must be 0 (by scene size) or 1..4");
         c->bvhLeafMax = value;
+        return PT_OK;
+    case 14:
+        if (value < 0 || value > 4095) return fail(PT_ERR_INVALID, "decoded-texture budget must be 0..4095 MiB");
+        c->textureDecodeBytes = (size_t)value << 20;
+        c->texturesDirty = true;
         return PT_OK;
     case 8:
         if (value < 1) return fail(PT_ERR_INVALID, "sample budget must be >= 1 MiB");

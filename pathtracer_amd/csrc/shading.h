@@ -31,7 +31,7 @@ struct DevScene {
     const DevMaterial* materials;
     const DevTexture* textures;
     const unsigned char* texels;
-    const float* srgbLut;  // 256 entries
+    const float* srgbLut;  // 512 entries: 8-bit channel -> float, unsigned-normalised | sRGB-decoded
     const float4* envColorPdf;  // per HDRI texel: rgb = radiance, w = cache pdf (cache.b)
     const float2* envSample;    // per cache texel: (cache.r, cache.g)
 };
@@ -81,34 +81,18 @@ PT_DEV float bilerp(const Bilerp& q, float t00, float t10, float t01, float t11)
     return mix_(mix_(t00, t10, q.a), mix_(t01, t11, q.a), q.b);
 }
 
+// One tap: the arena holds every texel with four channels (absent ones as 0, 0, 1), so a tap of an 8-bit texture is
+// one 32-bit read and four table lookups (table entries 0..255: b / 255; 256..511: sRGB decode; alpha stays linear),
+// a tap of a float texture one 16-byte read.
 PT_DEV float4 fetchTexel(const DevScene& S, const DevTexture& t, int x, int y)
 {
-    // (four scalars, not an array: an array indexed by the channel loop lives in scratch memory)
-    float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 1.0f;
-    const size_t idx = ((size_t)y * (size_t)t.width + (size_t)x) * (size_t)t.channels;
-    const int n = t.channels;  // 1..4
-    if (t.format == 2) {
-        const float* p = (const float*)(S.texels + t.offset) + idx;
-        o0 = p[0];
-        if (n > 1) o1 = p[1];
-        if (n > 2) o2 = p[2];
-        if (n > 3) o3 = p[3];
-    } else {
-        const unsigned char* p = S.texels + t.offset + idx;
-        const bool srgb = t.format == 1;
-        const unsigned b0 = p[0];
-        o0 = srgb ? S.srgbLut[b0] : (float)b0 / 255.0f;
-        if (n > 1) {
-            const unsigned b = p[1];
-            o1 = srgb ? S.srgbLut[b] : (float)b / 255.0f;
-        }
-        if (n > 2) {
-            const unsigned b = p[2];
-            o2 = srgb ? S.srgbLut[b] : (float)b / 255.0f;
-        }
-        if (n > 3) o3 = (float)p[3] / 255.0f;  // alpha stays linear
-    }
-    return make_float4(o0, o1, o2, o3);
+    // (32-bit byte offsets from the arena's base, which the host keeps below 4 GB: a scalar base and a lane offset)
+    const unsigned texel = (unsigned)y * (unsigned)t.width + (unsigned)x;
+    if (t.format == 2) return *reinterpret_cast<const float4*>(S.texels + ((unsigned)t.offset + texel * 16u));
+    const unsigned w = *reinterpret_cast<const unsigned*>(S.texels + ((unsigned)t.offset + texel * 4u));
+    const unsigned colour = t.format == 1 ? 256u : 0u;
+    return make_float4(S.srgbLut[colour + (w & 255u)], S.srgbLut[colour + ((w >> 8) & 255u)], S.srgbLut[colour + ((w >> 16) & 255u)],
+                       S.srgbLut[w >> 24]);
 }
 PT_DEV float4 sampleTexture(const DevScene& S, int texIndex, float u, float v)
 {

@@ -351,9 +351,15 @@ def _textured_quad_scene():
 
 
 @PIPELINES
-def test_textured_materials_bit_exact(pipeline):
+@pytest.mark.parametrize("decode_mib", [None, 0], ids=["texels-decoded-at-upload", "texels-8-bit"])
+def test_textured_materials_bit_exact(pipeline, decode_mib):
+    """All eleven slots bound, 8-bit (sRGB and linear, three and four channels) and float texels; the library keeps 8-bit
+    textures as decoded floats up to a byte budget (tuning `texture_decode_mib`) and as 8-bit words beyond it: both
+    forms must give the oracle's bits."""
     scene, tex = _textured_quad_scene()
     o, g = _pair(scene, 80, 80, textures=tex, pipeline=pipeline)
+    if decode_mib is not None:
+        g.set_tuning(texture_decode_mib=decode_mib)
     p = R.default_params(80, 80)
     g.set_params(p)
     g.clear()
@@ -362,6 +368,34 @@ def test_textured_materials_bit_exact(pipeline):
     cpu = o.render(p, 80, 80, 1, 3, 1)
     _assert_images_equal(gpu, cpu[:3], cpu[3], "textured quad")
     assert np.isfinite(gpu[0]).all()
+    # the other storage form, switched on the same context, renders the same bits again
+    g.set_tuning(texture_decode_mib=64 if decode_mib == 0 else 0)
+    g.clear()
+    g.dispatch(1, 3, 1)
+    for k in range(3):
+        assert g.read_image(k).tobytes() == gpu[k].tobytes()
+
+
+@pytest.mark.parametrize("decode_mib", [64, 0], ids=["texels-decoded-at-upload", "texels-8-bit"])
+def test_textures_of_one_and_two_channels_read_as_r001_and_rg01(decode_mib):
+    """A sampler returns (r, 0, 0, 1) for a one-channel texture and (r, g, 0, 1) for a two-channel one: the metallic-
+    roughness slot reads .x and .y, the specular slot .w (alpha: 1 without an alpha channel), the albedo slot rgb."""
+    scene, tex = _textured_quad_scene()
+    rng = np.random.default_rng(11)
+    names = list(scenes.TEXTURE_SLOTS)
+    for name, ch in (("metallicRoughness", 2), ("specular", 1), ("albedo", 1), ("clearcoatRoughness", 2)):
+        slot = names.index(name) + 1
+        tex[slot] = (rng.integers(32, 256, (9, 6, ch), dtype=np.uint8), name == "albedo")
+    tex[names.index("transmission") + 1] = (rng.uniform(0.1, 0.9, (5, 4, 1)).astype(np.float32), False)
+    o, g = _pair(scene, 64, 64, textures=tex)
+    g.set_tuning(texture_decode_mib=decode_mib)
+    p = R.default_params(64, 64)
+    g.set_params(p)
+    g.clear()
+    g.dispatch(1, 3, 1)
+    gpu = [g.read_image(k) for k in range(3)]
+    cpu = o.render(p, 64, 64, 1, 3, 1)
+    _assert_images_equal(gpu, cpu[:3], cpu[3], "one- and two-channel textures")
 
 
 def test_process_buffers_path_matches_manual_upload():

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Wave-occupancy profile of the megakernel on the benchmark workload (counting build).
-    python tools/occupancy_profile.py [spp] [key=value tuning settings ...]"""
+    python tools/occupancy_profile.py [spp] [key=value tuning settings ...]
+PT_PROFILE_SCENE picks another of bench.py's scenes, PT_PROFILE_BVH the builder, PT_PROFILE_REBUILD=0 the uploaded tree itself."""
 import os
 import sys
 
@@ -11,26 +12,22 @@ from pathtracer_amd import renderer as R  # noqa: E402
 
 
 class A:
-    subdivide = bench.DEFAULT_SUBDIVIDE
+    scene = os.environ.get("PT_PROFILE_SCENE", "dragonglass")  # any scene of bench.py
+    copies = 1
+    subdivide = bench.DEFAULT_SUBDIVIDE if scene in ("dragonglass", "closeup") else 0
     bvh = os.environ.get("PT_PROFILE_BVH", "host")  # host | full-sweep | device
 
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+_, W, H, bounces = bench.SCENES[A.scene]
 work = bench.build_workload(A)
-g = R.Renderer(1920, 1080)
+g = R.Renderer(W, H)
 g.set_bvh_rebuild(os.environ.get("PT_PROFILE_REBUILD", "1") == "1")
-if work["nodes"] is None:
-    g.build_bvh_device(work["prims"])
-else:
-    g.upload_nodes(work["nodes"]); g.upload_primitives(work["prims"])
-g.upload_materials(work["mats"])
-g.upload_environment(work["hdri"], work["cache"])
-p = R.default_params(1920, 1080)
-p.max_bounces = 8
-g.set_params(p)
 tuning = dict(item.split("=") for item in sys.argv[2:])
-if tuning:
+if tuning:  # (before the scene goes in: some settings steer the device builder)
     g.set_tuning(**{k: int(v) for k, v in tuning.items()})
+bench.install_scene(g, work)
+g.set_params(bench.scene_params(work, W, H, bounces))
 g.clear()
 g.dispatch(1, spp, 1)  # (leaves the tile costs the next launch is planned from)
 g.clear()
