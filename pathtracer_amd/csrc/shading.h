@@ -183,6 +183,10 @@ struct Surface {
     // lobe mixture, direction-independent part (disney.glsl:12-18,127-130)
     v3 Cspec0, Csheen;
     float lumAlbedo, lumDielectric, lumMetal;
+    // direction-independent terms of the lobe evaluators, taken once per hit instead of once per evaluated direction:
+    // the view-side Smith terms (brdf.glsl:50-56,70-75) and the refraction tint pow(albedo, 0.5) (disney.glsl:70)
+    float smithV1, lenV;
+    v3 glassTint;
 };
 
 struct Dir {
@@ -327,6 +331,13 @@ PT_DEV Surface makeSurface(const MaterialEval& m, v3 N, v3 V)
     float sw = schlickWeight(s.NdotV);
     s.lumDielectric = luminance(mix3(s.Cspec0, splat(1.0f), sw));
     s.lumMetal = luminance(mix3(m.albedo, splat(1.0f), sw));
+    const float absNdotV = abs_(s.NdotV);
+    const float ga = s.VdotX * s.ax, gb = s.VdotY * s.ay;
+    s.lenV = sqrt_(ga * ga + gb * gb + absNdotV * absNdotV);
+    s.smithV1 = (2.0f * absNdotV) / (absNdotV + s.lenV);
+    s.glassTint = splat(0.0f);
+    if ((1.0f - m.metallic) * m.transmission > 0.0f)  // (the glass lobe's weight: only then is the tint read)
+        s.glassTint = mk3(pow_(m.albedo.x, 0.5f), pow_(m.albedo.y, 0.5f), pow_(m.albedo.z, 0.5f));
     return s;
 }
 
@@ -473,9 +484,8 @@ PT_DEV v3 evaluateBsdf(const Surface& s, const Dir& d, float& pdfOut)
         float b2 = a2 / d2;
         D = a2 * b2 * b2 * kOneOverPi;
         float absNdotV = abs_(s.NdotV), absNdotL = abs_(d.NdotL);
-        float ga = s.VdotX * s.ax, gb = s.VdotY * s.ay;
-        V1 = (2.0f * absNdotV) / (absNdotV + sqrt_(ga * ga + gb * gb + absNdotV * absNdotV));
-        float lambdaV = absNdotL * length3(mk3(s.ax * s.VdotX, s.ay * s.VdotY, absNdotV));
+        V1 = s.smithV1;
+        float lambdaV = absNdotL * s.lenV;
         float lambdaL = absNdotV * length3(mk3(s.ax * d.LdotX, s.ay * d.LdotY, absNdotL));
         V2 = 0.5f / (lambdaV + lambdaL);
     }
@@ -526,8 +536,7 @@ PT_DEV v3 evaluateBsdf(const Surface& s, const Dir& d, float& pdfOut)
                 float eta2 = s.eta * s.eta;
                 float jacobian = abs_(d.LdotH) / denom;
                 pr = D * V1 * fmax_(0.0f, d.VdotH) * jacobian / s.NdotV;
-                v3 tint = mk3(pow_(s.albedo.x, 0.5f), pow_(s.albedo.y, 0.5f), pow_(s.albedo.z, 0.5f));
-                fr = tint * (splat(1.0f) - splat(F)) * D * V2 * abs_(d.VdotH) * jacobian * eta2 * 4.0f;
+                fr = s.glassTint * (splat(1.0f) - splat(F)) * D * V2 * abs_(d.VdotH) * jacobian * eta2 * 4.0f;
             }
             f = f + fr * l.glassWeight;
             pdf = pdf + pr * l.pGlass * (1.0f - F);

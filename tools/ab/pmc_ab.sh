@@ -1,9 +1,9 @@
-# usage: bash tools/ab/pmc_ab.sh <outdir> lib...   : SQ instruction counters of the headline launch per library
+# usage: [PT_AB_ARGS="--scene interior"] bash tools/ab/pmc_ab.sh <outdir> lib...   : SQ instruction counters of the benchmark launch per library
 set -u
 out=$1; shift
 mkdir -p $out
 export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-device-tree --no-frame-by-frame"
+ARGS="${PT_AB_ARGS:-} --steps 2 --warmup 1 --no-cpu-baseline --no-device-tree --no-frame-by-frame"
 for lib in "$@"; do
   tag=$(basename $lib .so)
   PT_LIBPTCORE=$PWD/$lib timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d $out/$tag -- python3 bench.py $ARGS > $out/$tag.log 2>&1 || { echo "pass failed for $tag"; tail -3 $out/$tag.log; exit 1; }
