@@ -504,9 +504,24 @@ PT_DEV void startSample(const DevParams& P, unsigned px, unsigned py, PathState&
 // returns the rays the bounce wants traced, none at all meaning that the path has ended).  Both kinds of lane go
 // through ONE environment lookup -- a miss looks along its ray, a hit towards the light direction it has just
 // sampled -- so that a wave with lanes of either kind pays for that code once, at the fill of both together.
+#ifdef PT_EXPERIMENT_SHADE_TIMERS  // where a shading block's ticks go: wave clock between marks, summed per wave in LDS, flushed at the kernel's end
+__device__ unsigned long long g_shadeTicks[8];
+__shared__ unsigned long long s_shadeTicks[8];
+#define PT_MARK(i)                                                              \
+    {                                                                           \
+        const unsigned long long now_ = __builtin_readcyclecounter();           \
+        if (threadIdx.x == __builtin_ctzll(__ballot(1))) s_shadeTicks[i] += now_ - mark_; \
+        mark_ = __builtin_readcyclecounter();                                   \
+    }
+#else
+#define PT_MARK(i)
+#endif
 PT_DEV BounceRays shadeRay(const DevParams& P, const DevScene& S, PathState& ps, v3 ro, v3 rd, int prim, float tHit, float uHit,
                            float vHit, bool isHit)
 {
+#ifdef PT_EXPERIMENT_SHADE_TIMERS
+    unsigned long long mark_ = __builtin_readcyclecounter();
+#endif
     BounceRays out;
     out.hasShadow = false;
     out.hasExt = false;
@@ -538,8 +553,10 @@ PT_DEV BounceRays shadeRay(const DevParams& P, const DevScene& S, PathState& ps,
         mw = loadMaterial(S, meshIndex);
         normalMap = S.materials[meshIndex].tex[kTexNormal];
     }
+    PT_MARK(0)
     float pdfLight = 0.0f;
     const v3 colorLight = evaluateHdri(S, P.envW, P.envH, P.hdriW, P.hdriH, lookDir, pdfLight);
+    PT_MARK(1)
     if (!isHit) {
         float misWeight = 1.0f;
         if (ps.bounce > 0u) {
@@ -559,8 +576,10 @@ PT_DEV BounceRays shadeRay(const DevParams& P, const DevScene& S, PathState& ps,
         tangent = (mk3(q1.x, q1.y, q1.z) * dCy - mk3(q2.x, q2.y, q2.z) * dBy) * invTd;
     }
     const MaterialEval me = evaluateMaterial(S, P, mw, meshIndex, uvx, uvy, N, tangent);
+    PT_MARK(2)
     const v3 V = -rd;
     const Surface surf = makeSurface(me, N, V);
+    PT_MARK(3)
     ps.radiance = ps.radiance + ps.throughput * surf.emission;
     out.origin = offsetRay(P0, Ng);  // shared by the shadow and the extension ray (:66,:131)
 
@@ -581,8 +600,10 @@ PT_DEV BounceRays shadeRay(const DevParams& P, const DevScene& S, PathState& ps,
         out.shadowDir = Ll;
     }
 
+    PT_MARK(4)
     // BSDF sampling, Russian roulette, next ray (pathtracing.comp:104-139)
     const v3 L = sampleBsdf(surf, ps.rng);
+    PT_MARK(5)
     const Dir ds = makeDir(surf, L);
     ps.pdfBsdf = 0.0f;
     ps.f = evaluateBsdf(surf, ds, ps.pdfBsdf);
@@ -600,6 +621,7 @@ PT_DEV BounceRays shadeRay(const DevParams& P, const DevScene& S, PathState& ps,
             out.extDir = L;
         }
     }
+    PT_MARK(6)
     return out;
 }
 
@@ -754,6 +776,10 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
     if (COUNT && lane < 32u) s_depth[lane] = 0u;
     int* stack = s_stack + lane;
     stack[0] = 0;  // row 0 of the stack column: "no entry"
+#ifdef PT_EXPERIMENT_SHADE_TIMERS
+    if (lane < 8u) s_shadeTicks[lane] = 0ull;
+    __syncthreads();
+#endif
 
     // Work items.  An item is a tile's (pixel, sample) pairs for a range of the launch's samples: the
     // whole range, tile after tile, without cost information; with it, the entries of the list the
@@ -991,6 +1017,10 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
         if (COUNT) prof[13] += __builtin_readcyclecounter() - tick;
     }
 
+#ifdef PT_EXPERIMENT_SHADE_TIMERS
+    __syncthreads();
+    if (lane < 8u) atomicAdd(&g_shadeTicks[lane], s_shadeTicks[lane]);
+#endif
     // counters: wave-level reduction, one atomic per wave and counter
     const unsigned sRays = waveSum(nRays), sShadow = waveSum(nShadow), sHits = waveSum(nHits), sSamples = waveSum(nSamples);
     const unsigned nSamplesWave = __builtin_amdgcn_readfirstlane(sSamples);

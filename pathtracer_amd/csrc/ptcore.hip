@@ -1541,6 +1541,18 @@ int pt_scene_bytes(pt_ctx* c, uint64_t* nodeBytes, uint64_t* triangleBytes, uint
 // (0 = the default, 3); 12: the trace launches of consecutive dispatch calls may overlap (1), never do (0), or do for
 // calls of at most 8 frames (-1, the default); 13: device BVH builder: most triangles per leaf (1..4; 0, the default: 2 for
 // scenes of up to 1.3 M triangles, 4 above).
+#ifdef PT_EXPERIMENT_SHADE_TIMERS
+// Experiment builds only: the tick sums of shadeRay's sections since the last call (and resets them).
+extern "C" int pt_experiment_shade_ticks(unsigned long long* out8)
+{
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(ptcore::g_shadeTicks), sizeof(zero)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(ptcore::g_shadeTicks), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+
 int pt_debug_set_tuning(pt_ctx* c, int key, int value)
 {
     if (!c) return fail(PT_ERR_INVALID, "null context");
