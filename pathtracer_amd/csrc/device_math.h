@@ -135,32 +135,36 @@ PT_DEV float asin_(float xx)
     return neg ? -r : r;
 }
 
+// (One division serves both reduced ranges: -(1 / x) is (-1) / x bit for bit, rounding being symmetric in sign;
+// lanes of a wave that fall into different ranges then share one copy of the division's code.)
 PT_DEV float atan1_(float xx)
 {
     bool neg = xx < 0.0f;
     float x = abs_(xx);
-    float y;
-    if (x > 2.414213562373095f) {
-        y = 1.5707963267948966192f;
-        x = -(1.0f / x);
-    } else if (x > 0.4142135623730950f) {
-        y = 0.7853981633974483096f;
-        x = (x - 1.0f) / (x + 1.0f);
-    } else {
-        y = 0.0f;
+    const bool high = x > 2.414213562373095f, mid = x > 0.4142135623730950f;
+    float y = high ? 1.5707963267948966192f : (mid ? 0.7853981633974483096f : 0.0f);
+    if (mid) {  // (`high` implies `mid`)
+        const float num = high ? -1.0f : x - 1.0f;
+        const float den = high ? x : x + 1.0f;
+        x = num / den;
     }
     float z = x * x;
     y = y + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x);
     return neg ? -y : y;
 }
+// (The quotient and its arctangent are taken once for every x != 0 and the quadrant's offset added afterwards: the
+// same operations per lane as a branch per quadrant, in one copy of the code.)
 PT_DEV float atan2_(float y, float x)
 {
     const float pi = 3.14159265358979323846f;
-    if (x > 0.0f) return atan1_(y / x);
-    if (x < 0.0f) return (y >= 0.0f) ? atan1_(y / x) + pi : atan1_(y / x) - pi;
-    if (y > 0.0f) return 1.5707963267948966192f;
-    if (y < 0.0f) return -1.5707963267948966192f;
-    return 0.0f;
+    if (!(x > 0.0f) && !(x < 0.0f)) {  // x is zero (or a NaN)
+        if (y > 0.0f) return 1.5707963267948966192f;
+        if (y < 0.0f) return -1.5707963267948966192f;
+        return 0.0f;
+    }
+    const float t = atan1_(y / x);
+    if (x > 0.0f) return t;
+    return (y >= 0.0f) ? t + pi : t - pi;
 }
 
 PT_DEV float scalePow2(float v, int n)
