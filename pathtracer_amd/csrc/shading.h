@@ -438,30 +438,52 @@ PT_DEV v3 sampleBsdf(const Surface& s, unsigned& rng)
     float xi1 = randomValue(rng);
     float xi2 = randomValue(rng);
     float rd = randomValue(rng);
-    if (rd < c0 || (!(rd < c2) && !(rd < c3) && rd < c4)) {  // diffuse or sheen: cosine hemisphere
-        return toWorld(s, hemispherePointCos(xi1, xi2));
-    } else if (rd < c2 || rd < c3) {  // dielectric + metal reflection (rd < c2), or glass
-        v3 tangentV = mk3(dot(s.X, s.V), dot(s.Y, s.V), dot(s.N, s.V));
-        v3 H = sampleVisibleGGX(tangentV, s.ax, s.ay, xi1, xi2);
-        if (H.z < 0.0f) H = -H;
-        H = toWorld(s, H);
-        if (rd < c2) return normalize3(reflect3(-s.V, H));
-        float F = fresnelDielectric(abs_(dot(s.V, H)), s.eta);
-        float rr = fmin_((rd - c2) / (c3 - c2), 0.99999994f);  // RescaleRandomNumber, montecarlo.glsl:118-122
-        if (rr < F) return normalize3(reflect3(-s.V, H));
-        return normalize3(refract3(-s.V, H, s.eta));
-    } else {  // clearcoat: GGX NDF (montecarlo.glsl:63-76)
+    // The lobes' samplers share their building blocks: a sine / cosine pair of one azimuth, a direction built in the
+    // tangent frame and taken to the world, and (all but the cosine lobe) a reflection about that direction.  Each is
+    // written once here, with the per-lobe operands selected beforehand, so that a wave whose lanes picked different
+    // lobes runs one copy of them; every lane still performs its lobe's operations in its lobe's order.
+    const bool cosine = rd < c0 || (!(rd < c2) && !(rd < c3) && rd < c4);  // diffuse or sheen: cosine hemisphere
+    const bool ggx = !cosine && (rd < c2 || rd < c3);  // dielectric + metal reflection (rd < c2), or glass
+    const bool coat = !cosine && !ggx;                 // clearcoat: GGX NDF (montecarlo.glsl:63-76)
+    float sp, cp;
+    sincos_(kTwoPi * (coat ? xi1 : xi2), sp, cp);  // (montecarlo.glsl:55 has the factors the other way round: same product)
+    v3 local;
+    if (cosine) {  // montecarlo.glsl:53-59
+        float cosTheta = sqrt_(1.0f - xi1);
+        float sinTheta = sqrt_(1.0f - cosTheta * cosTheta);
+        local = mk3(cp * sinTheta, sp * sinTheta, cosTheta);
+    } else if (ggx) {  // visible normals of the anisotropic GGX (montecarlo.glsl:83-106)
+        v3 Ve = mk3(dot(s.X, s.V), dot(s.Y, s.V), dot(s.N, s.V));
+        v3 Vh = normalize3(mk3(s.ax * Ve.x, s.ay * Ve.y, Ve.z));
+        float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+        v3 T1 = lensq > 0.0f ? mk3(-Vh.y, Vh.x, 0.0f) * rsqrt_(lensq) : mk3(1.0f, 0.0f, 0.0f);
+        v3 T2 = cross(Vh, T1);
+        float r = sqrt_(xi1);
+        float t1 = r * cp;
+        float t2 = r * sp;
+        float sh = 0.5f * (1.0f + Vh.z);
+        t2 = mix_(sqrt_(1.0f - t1 * t1), t2, sh);
+        v3 Nh = t1 * T1 + t2 * T2 + sqrt_(fmax_(0.0f, 1.0f - t1 * t1 - t2 * t2)) * Vh;
+        local = normalize3(mk3(s.ax * Nh.x, s.ay * Nh.y, fmax_(0.0f, Nh.z)));
+    } else {
         float a2 = s.alphaClearcoat * s.alphaClearcoat;
         float cosThetaH = sqrt_((1.0f - xi2) / (1.0f + (a2 - 1.0f) * xi2));
         float sinThetaH = sqrt_(fmax_(0.0f, 1.0f - cosThetaH * cosThetaH));
-        float phiH = kTwoPi * xi1;
-        float sp, cp;
-        sincos_(phiH, sp, cp);
-        v3 H = mk3(sinThetaH * cp, sinThetaH * sp, cosThetaH);
-        if (H.z < 0.0f) H = -H;
-        H = toWorld(s, H);
-        return normalize3(reflect3(-s.V, H));
+        local = mk3(sinThetaH * cp, sinThetaH * sp, cosThetaH);
     }
+    if (!cosine && local.z < 0.0f) local = -local;
+    const v3 w = toWorld(s, local);
+    if (cosine) return w;
+    // `w` is the half vector: reflect about it, or (glass, when the rescaled random falls beyond the Fresnel term) refract
+    bool refracts = false;
+    if (ggx && !(rd < c2)) {
+        float F = fresnelDielectric(abs_(dot(s.V, w)), s.eta);
+        float rr = fmin_((rd - c2) / (c3 - c2), 0.99999994f);  // RescaleRandomNumber, montecarlo.glsl:118-122
+        refracts = !(rr < F);
+    }
+    v3 out = reflect3(-s.V, w);
+    if (refracts) out = refract3(-s.V, w, s.eta);
+    return normalize3(out);
 }
 
 // EvaluateDisneyBrdf (disney.glsl:243-346) with its lobe evaluators (:20-104).
@@ -510,8 +532,20 @@ PT_DEV v3 evaluateBsdf(const Surface& s, const Dir& d, float& pdfOut)
             pdf = pdf + 0.0f * l.pDiffuse;
         }
     }
-    if (l.pDielectric > 0.0f && reflection) {
-        float F = (fresnelDielectric(VdotH, 1.0f / s.refraction) - s.f0) / (1.0f - s.f0);
+    // The dielectric lobe wants the Fresnel term at 1 / ior, the glass lobe at eta, which IS 1 / ior seen from outside
+    // and ior seen from inside.  A lane with one of the two lobes (transmission 0 or 1), or seen from outside, needs
+    // one term: those share the first evaluation below, each lane at its own index; only a lane with both lobes seen
+    // from inside takes the second.
+    const bool wantDielectric = l.pDielectric > 0.0f && reflection, wantGlass = l.pGlass > 0.0f;
+    const bool inside = s.NdotV <= 0.0f;  // (eta = ior)
+    float fresnelFirst = 0.0f, fresnelGlass = 0.0f;
+    if (wantDielectric || wantGlass) {
+        fresnelFirst = fresnelDielectric(VdotH, wantDielectric ? 1.0f / s.refraction : s.eta);
+        fresnelGlass = fresnelFirst;
+        if (wantDielectric && wantGlass && inside) fresnelGlass = fresnelDielectric(VdotH, s.eta);
+    }
+    if (wantDielectric) {
+        float F = (fresnelFirst - s.f0) / (1.0f - s.f0);
         v3 Fc = mix3(s.Cspec0, splat(1.0f), F);
         f = f + (front ? Fc * D * V2 : splat(0.0f)) * l.dielectricWeight;
         pdf = pdf + (front ? pdfReflect : 0.0f) * l.pDielectric;
@@ -521,8 +555,8 @@ PT_DEV v3 evaluateBsdf(const Surface& s, const Dir& d, float& pdfOut)
         f = f + (front ? Fc * D * V2 : splat(0.0f)) * l.metalWeight;
         pdf = pdf + (front ? pdfReflect : 0.0f) * l.pMetal;
     }
-    if (l.pGlass > 0.0f) {
-        float F = fresnelDielectric(VdotH, s.eta);
+    if (wantGlass) {
+        float F = fresnelGlass;
         if (reflection) {
             f = f + (front ? splat(F) * D * V2 : splat(0.0f)) * l.glassWeight;
             pdf = pdf + (front ? pdfReflect : 0.0f) * l.pGlass * F;
