@@ -24,3 +24,5 @@ tot = sum(t[:7])
 print(A.scene, "ms", g.last_dispatch_ms())
 for n, v in zip(names, t):
     print(f"  {n:42s} {v / tot:6.1%}  {v:.3e}")
+if os.environ.get("PT_SHADE_TICKS_RAW"):
+    print("  raw", t)
