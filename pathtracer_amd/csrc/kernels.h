@@ -174,6 +174,17 @@ PT_DEV void stackPop(Query& q, const int* stack, const int* deep)
     q.top = stackGet<STRIDE, LDS_DEPTH>(stack, deep, q.sp);
 }
 
+// Fills in the material records' refraction tint, pow(albedo, 0.5) per channel, with the device's own pow: a hit then
+// reads it instead of taking three pow (the shader takes them per evaluated direction, disney.glsl:70).
+__global__ void materialTintKernel(DevMaterial* __restrict__ mats, unsigned count)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    mats[i].glassTint[0] = pow_(mats[i].albedo[0], 0.5f);
+    mats[i].glassTint[1] = pow_(mats[i].albedo[1], 0.5f);
+    mats[i].glassTint[2] = pow_(mats[i].albedo[2], 0.5f);
+}
+
 // The traversal kernels walk a four-wide tree made of the binary one, level by level from the root (one launch
 // of collapseKernel per level: `frontier` holds (binary node, index of its wide node) pairs, `counters` the next
 // free wide node and the size of the next frontier).  A wide node starts from the binary node's two children;
@@ -535,7 +546,7 @@ PT_DEV BounceRays shadeRay(const DevParams& P, const DevScene& S, PathState& ps,
     float uvx = 0.0f, uvy = 0.0f;
     unsigned meshIndex = 0u;
     int normalMap = -1;
-    MaterialWords mw{s0, s0, s0, s0, s0};
+    MaterialWords mw{s0, s0, s0, s0, s0, s0};
     v3 lookDir = rd;
     if (isHit) {
         // hit attributes of the winning triangle (intersection.glsl:41-57)

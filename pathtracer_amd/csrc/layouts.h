@@ -167,9 +167,11 @@ struct alignas(16) DevMaterial {
     float refraction, transmission;
     uint32_t anyTexture;  // non-zero when at least one of tex[] is set
     uint32_t pad;
+    float glassTint[3];  // pow(albedo, 0.5) per channel (the refraction lobe's tint, disney.glsl:70), filled in on the device at upload
+    uint32_t pad2;
     int32_t tex[12];  // kTexSlotCount entries used; index into DevTexture table, -1 = none
 };
-static_assert(sizeof(DevMaterial) == 128, "");
+static_assert(sizeof(DevMaterial) == 144, "");
 
 struct DevTexture {
     uint64_t offset;  // byte offset into the texel arena

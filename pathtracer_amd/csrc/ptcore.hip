@@ -408,6 +408,9 @@ int syncScene(pt_ctx* c)
         if (!err.empty()) return fail(PT_ERR_SCENE, err);
         HIP_TRY(c->dMaterials.ensure(packed.size() * sizeof(DevMaterial)));
         HIP_TRY(hipMemcpyAsync(c->dMaterials.ptr, packed.data(), packed.size() * sizeof(DevMaterial), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(materialTintKernel, dim3(((unsigned)packed.size() + 63u) / 64u), dim3(64), 0, c->stream,
+                           (DevMaterial*)c->dMaterials.ptr, (unsigned)packed.size());
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->materialsDirty = false;
         c->forkDirty = true;

@@ -205,17 +205,19 @@ struct MaterialEval {
     v3 emission, albedo;
     float specular, specularTint, metallic, roughness, subsurface, anisotropy, sheenRoughness, sheenTint, clearcoat,
         clearcoatRoughness, refraction, transmission;
+    v3 glassTint;       // pow(albedo, 0.5) as the material record holds it ...
+    bool tintOnRecord;  // ... which stands unless a texture has modulated the albedo
 };
 
 // The material record's scalar part as loaded (requested as early as the hit's material index is known, so that
 // the reads are under way while the caller does other work).
 struct MaterialWords {
-    float4 m0, m1, m2, m3, m4;
+    float4 m0, m1, m2, m3, m4, m5;
 };
 PT_DEV MaterialWords loadMaterial(const DevScene& S, unsigned meshIndex)
 {
     const float4* mp = (const float4*)(S.materials + meshIndex);
-    return MaterialWords{mp[0], mp[1], mp[2], mp[3], mp[4]};
+    return MaterialWords{mp[0], mp[1], mp[2], mp[3], mp[4], mp[5]};
 }
 
 // `shadingNormal` is rewritten when a normal map is bound (utility.glsl:108-111).
@@ -238,6 +240,8 @@ PT_DEV MaterialEval evaluateMaterial(const DevScene& S, const DevParams& P, cons
     e.clearcoatRoughness = m3.w;
     e.refraction = m4.x;
     e.transmission = m4.y;
+    e.glassTint = mk3(mw.m5.x, mw.m5.y, mw.m5.z);
+    e.tintOnRecord = true;
     if (__float_as_uint(m4.z) != 0u) {  // anyTexture
         const int* tex = S.materials[meshIndex].tex;
         if (tex[kTexEmission] >= 0) {
@@ -247,6 +251,7 @@ PT_DEV MaterialEval evaluateMaterial(const DevScene& S, const DevParams& P, cons
         if (tex[kTexAlbedo] >= 0) {
             float4 s = sampleTexture(S, tex[kTexAlbedo], u, v);
             e.albedo = e.albedo * mk3(s.x, s.y, s.z);
+            e.tintOnRecord = false;
         }
         if (tex[kTexNormal] >= 0) {  // SampleNormalMap, utility.glsl:69-92
             v3 N = shadingNormal;
@@ -335,8 +340,9 @@ PT_DEV Surface makeSurface(const MaterialEval& m, v3 N, v3 V)
     const float ga = s.VdotX * s.ax, gb = s.VdotY * s.ay;
     s.lenV = sqrt_(ga * ga + gb * gb + absNdotV * absNdotV);
     s.smithV1 = (2.0f * absNdotV) / (absNdotV + s.lenV);
-    s.glassTint = splat(0.0f);
-    if ((1.0f - m.metallic) * m.transmission > 0.0f)  // (the glass lobe's weight: only then is the tint read)
+    // (read only when the glass lobe has weight; the three pow are taken here only where a texture has changed the albedo)
+    s.glassTint = m.glassTint;
+    if (!m.tintOnRecord && (1.0f - m.metallic) * m.transmission > 0.0f)
         s.glassTint = mk3(pow_(m.albedo.x, 0.5f), pow_(m.albedo.y, 0.5f), pow_(m.albedo.z, 0.5f));
     return s;
 }
