@@ -317,8 +317,14 @@ PT_DEV int queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc, 
     const float4 t0 = trec[0], t1 = trec[1], t2 = trec[2];
     bool finished = false;  // query complete
     bool pop = false;
-    if (hasNode) {
-        if (COUNT) sc.nodeVisits++;
+    // Both halves run for every calling lane, unbranched -- a lane without a node visits record 0 and a lane without a
+    // triangle tests record 0, their results masked -- which keeps all seven reads at the head of the step, the node's
+    // ahead of the triangle's.  Reads return in order: the node half, first to use its data, then waits for the node
+    // only, and the triangle's record has the node half's instructions to arrive in.  (Given a branch around either
+    // half the compiler moves that half's reads into it, behind the other half: two round trips a step, or the node
+    // waiting for the triangle.  1.5-3 % of the launch.)
+    {
+        if (COUNT) sc.nodeVisits += hasNode;
 #ifdef PT_EXPERIMENT_EXTRA_LOAD
         asm volatile("" ::"v"(extraRead.x));
 #endif
@@ -372,6 +378,7 @@ PT_DEV int queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc, 
         // writes the row above the stack's top, which nothing reads.
         // (an empty slot has reference 0 and an inverted box; should a degenerate grid let a ray into it all the
         // same, it must not pose as the nearest child: the keys go by the references)
+        h0 &= hasNode, h1 &= hasNode, h2 &= hasNode, h3 &= hasNode;
         int r0 = h0 ? kids.x : 0, r1 = h1 ? kids.y : 0, r2 = h2 ? kids.z : 0, r3 = h3 ? kids.w : 0;
         float k0 = r0 != 0 ? d0 : kFltMax, k1 = r1 != 0 ? d1 : kFltMax, k2 = r2 != 0 ? d2 : kFltMax, k3 = r3 != 0 ? d3 : kFltMax;
 #define PT_CSWAP(ka, ra, kb, rb)       \
@@ -400,12 +407,12 @@ PT_DEV int queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc, 
         q.sp += p1;
         if (COUNT) sc.maxStack = (unsigned)q.sp > sc.maxStack ? (unsigned)q.sp : sc.maxStack;
         q.cur = r0 != 0 ? r0 : q.cur;
-        pop = r0 == 0;
+        pop = hasNode & (r0 == 0);
     }
-    if (doTri) {
+    {
         // Moller-Trumbore with the shader's expressions (intersection.glsl:26-40); the edges and
         // their cross product come precomputed from the host.
-        if (COUNT) sc.triangleTests++;
+        if (COUNT) sc.triangleTests += doTri;
         const v3 n = mk3(t0.w, t1.w, t2.w);
         const v3 ab = mk3(t1.x, t1.y, t1.z), ac = mk3(t2.x, t2.y, t2.z);
         const v3 ao = q.ro - mk3(t0.x, t0.y, t0.z);
@@ -416,14 +423,14 @@ PT_DEV int queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc, 
         const float u = dot(ac, dao) * invDet;
         const float v = -dot(ab, dao) * invDet;
         const float w = 1.0f - u - v;
-        const bool ok = (det >= 1e-10f) & (dst >= 0.0f) & (u >= 0.0f) & (v >= 0.0f) & (w >= 0.0f);
+        const bool ok = doTri & (det >= 1e-10f) & (dst >= 0.0f) & (u >= 0.0f) & (v >= 0.0f) & (w >= 0.0f);
         // (for a shadow query only `occluded` below counts; what it keeps as its best hit is not read)
         const bool better = ok & (dst < q.bestT);
         q.bestT = better ? dst : q.bestT;
         q.bestU = better ? u : q.bestU;
         q.bestV = better ? v : q.bestV;
         q.bestPrim = better ? (int)q.leafPos : q.bestPrim;
-        q.leafPos++;
+        q.leafPos += doTri ? 1u : 0u;
         finished = q.isShadow & ok;  // occluded
     }
     if (pop) stackPop<STRIDE, LDS_DEPTH>(q, stack, deep);  // no child entered: next sub-tree off the stack
