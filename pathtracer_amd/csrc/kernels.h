@@ -938,9 +938,12 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
         if (mode == kModeFinish) {
             const unsigned px = pixel & 0xffffu, py = pixel >> 16;
             SampleRecord* rec = reinterpret_cast<SampleRecord*>(P.samples) + ((size_t)ps.k * P.pixels + ((size_t)py * P.width + px));
-            rec->radiance = ps.radiance;
-            rec->albedo = ps.albedoRes;
-            rec->normal = ps.normalRes;
+            // (written once, read once by resolveKernel after the launch: stored past the caches' retention, so that
+            // 36 bytes a sample do not push scene data out of the L2s)
+            float* rf = reinterpret_cast<float*>(rec);
+            __builtin_nontemporal_store(ps.radiance.x, rf + 0), __builtin_nontemporal_store(ps.radiance.y, rf + 1), __builtin_nontemporal_store(ps.radiance.z, rf + 2);
+            __builtin_nontemporal_store(ps.albedoRes.x, rf + 3), __builtin_nontemporal_store(ps.albedoRes.y, rf + 4), __builtin_nontemporal_store(ps.albedoRes.z, rf + 5);
+            __builtin_nontemporal_store(ps.normalRes.x, rf + 6), __builtin_nontemporal_store(ps.normalRes.y, rf + 7), __builtin_nontemporal_store(ps.normalRes.z, rf + 8);
             mode = kModeNew;
         }
         // lanes without a sample take the next (pixel, sample) pairs of the pool, and of the next item

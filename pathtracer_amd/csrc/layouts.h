@@ -202,7 +202,7 @@ struct DevParams {
     const unsigned int* blockCount; // megakernel: entries of blockList in use
     unsigned int* tileCost;         // megakernel: per tile, ticks waves spent on its items (input of the next launch's order)
     unsigned int* workNext;         // megakernel: next work item to hand out (zeroed before the launch)
-    float* samples;                 // megakernel: finished samples, 3 x float4 per (sample, pixel), sample-major
+    float* samples;                 // megakernel: finished samples, nine floats (radiance, albedo, normal) per (sample, pixel), sample-major
     unsigned long long pixels;      // width * height
     unsigned long long* waveTimes;  // counting build: per tile, wall-clock ticks at wave start and end (or null)
     uint32_t refillMin;    // wavefront: a wave refills from the ray queue once this many lanes are idle
