@@ -477,7 +477,8 @@ def main():
                          "waves_per_simd, l2_hit, l2_request_gbps, l1_l2_read_latency_cycles, limited_by. achieved counts ALGORITHMIC bytes: on a cache-resident scene the vector L1s "
                          "and the L2s serve them, so frac_hbm can exceed 1 and peak is the L2s' measured aggregate; traffic / "
                          "fabric_gbps are the bytes leaving the L2s; l1_busy / l1_stall: share of the CUs' cycles in which the vector "
-                         "L1 takes an access, one per cycle, or is held up by misses in flight (the two always add up to 1)"),
+                         "L1 takes an access, one per cycle, or is held up by misses in flight (the two always add up to 1); lane_utilisation counts a "
+                         "lane as active while it runs the half of the unbranched traversal step it has no use for (on record 0, results masked)"),
                 "frac_l2": achieved / L2_PEAK_GBS,
                 "fabric_gbps": (traffic / avg_kernel_s / 1e9) if traffic else None,
                 "fabric_frac": ((traffic / avg_kernel_s / 1e9) / (MALL_GATHER_GBS if cache_resident else HBM_PEAK_GBS)) if traffic else None,
