@@ -585,6 +585,10 @@ PT_DEV BounceRays shadeRay(const DevParams& P, const DevScene& S, PathState& ps,
         return out;
     }
     const v3 Ll = lookDir;
+    // (The two words of the material record that steer branches are made opaque here, after the environment lookup:
+    // left alone, the compiler tests them where they are loaded, and the wave sits out the material's round trip
+    // before it starts on the lookup's arithmetic.)
+    asm volatile("" : "+v"(normalMap), "+v"(mw.m4.z));
     v3 tangent = splat(0.0f);
     if (normalMap >= 0) {
         const float4* tp = reinterpret_cast<const float4*>(S.triangles + prim);
