@@ -562,7 +562,9 @@ PT_DEV BounceRays shadeRay(const DevParams& P, const DevScene& S, PathState& ps,
         const float4* shp = reinterpret_cast<const float4*>(S.shading + prim);
         s0 = shp[0], s1 = shp[1], s2 = shp[2], s3 = shp[3];
         const float4 s4 = shp[4];
-        lookDir = sampleHdri(S, P.envW, P.envH, ps.rng);
+        // (the light direction's table entries are requested first and used last: the hit's attributes and the
+        // material's reads go in between)
+        const SampleTaps taps = requestSampleHdri(S, P.envW, P.envH, ps.rng);
         uvx = s0.w * w + s2.w * uHit + s3.y * vHit;
         uvy = s1.w * w + s3.x * uHit + s3.z * vHit;
         N = normalize3(mk3(s0.x, s0.y, s0.z) * w + mk3(s1.x, s1.y, s1.z) * uHit + mk3(s2.x, s2.y, s2.z) * vHit);
@@ -570,6 +572,7 @@ PT_DEV BounceRays shadeRay(const DevParams& P, const DevScene& S, PathState& ps,
         meshIndex = __float_as_uint(s3.w);
         mw = loadMaterial(S, meshIndex);
         normalMap = S.materials[meshIndex].tex[kTexNormal];
+        lookDir = finishSampleHdri(taps);
     }
     PT_MARK(0)
     float pdfLight = 0.0f;

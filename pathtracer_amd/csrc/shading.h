@@ -105,16 +105,27 @@ PT_DEV float4 sampleTexture(const DevScene& S, int texIndex, float u, float v)
 }
 
 // ---- HDRI: hdri.glsl:6-54
-// SampleHdri: one bilinear tap of the (discontinuous) inverse-CDF table at two randoms.
-PT_DEV v3 sampleHdri(const DevScene& S, int envW, int envH, unsigned& rng)
+// SampleHdri: one bilinear tap of the (discontinuous) inverse-CDF table at two randoms, in two halves -- the first
+// draws the randoms and requests the four table entries, the second turns them into a direction -- so that a caller
+// can put work that needs neither between the request and the use.
+struct SampleTaps {
+    Bilerp q;
+    float2 t00, t10, t01, t11;
+};
+PT_DEV SampleTaps requestSampleHdri(const DevScene& S, int envW, int envH, unsigned& rng)
 {
+    SampleTaps e;
     float xi1 = randomValue(rng);
     float xi2 = randomValue(rng);
-    Bilerp q = bilerpSetup(xi1, xi2, envW, envH);
-    float2 t00 = S.envSample[(size_t)q.y0 * envW + q.x0], t10 = S.envSample[(size_t)q.y0 * envW + q.x1];
-    float2 t01 = S.envSample[(size_t)q.y1 * envW + q.x0], t11 = S.envSample[(size_t)q.y1 * envW + q.x1];
-    float ux = bilerp(q, t00.x, t10.x, t01.x, t11.x);
-    float uy = bilerp(q, t00.y, t10.y, t01.y, t11.y);
+    e.q = bilerpSetup(xi1, xi2, envW, envH);
+    e.t00 = S.envSample[(size_t)e.q.y0 * envW + e.q.x0], e.t10 = S.envSample[(size_t)e.q.y0 * envW + e.q.x1];
+    e.t01 = S.envSample[(size_t)e.q.y1 * envW + e.q.x0], e.t11 = S.envSample[(size_t)e.q.y1 * envW + e.q.x1];
+    return e;
+}
+PT_DEV v3 finishSampleHdri(const SampleTaps& e)
+{
+    float ux = bilerp(e.q, e.t00.x, e.t10.x, e.t01.x, e.t11.x);
+    float uy = bilerp(e.q, e.t00.y, e.t10.y, e.t01.y, e.t11.y);
     uy = 1.0f - uy;
     float phi = kTwoPi * (ux - 0.5f);
     float theta = kPi * (uy - 0.5f);
@@ -122,6 +133,11 @@ PT_DEV v3 sampleHdri(const DevScene& S, int envW, int envH, unsigned& rng)
     sincos_(theta, st, ct);
     sincos_(phi, sp, cp);
     return mk3(ct * cp, st, ct * sp);
+}
+PT_DEV v3 sampleHdri(const DevScene& S, int envW, int envH, unsigned& rng)
+{
+    const SampleTaps e = requestSampleHdri(S, envW, envH, rng);
+    return finishSampleHdri(e);
 }
 // EvaluateHdri: radiance and solid-angle pdf towards L (colour and pdf share one 4-texel fetch).
 PT_DEV v3 evaluateHdri(const DevScene& S, int envW, int envH, float hdriW, float hdriH, v3 L, float& pdf)
