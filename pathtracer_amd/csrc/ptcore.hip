@@ -141,6 +141,9 @@ struct pt_ctx {
         DeviceBuffer dPartsInOrder, dBlockStart, dBlockList, dBlockCount, dScanTemp;
         size_t tileCostTiles = 0, tileSortBytes = 0, scanBytes = 0, blockCapacity = 0;
         bool tileCostValid = false;
+        // the item list on record: made for launches of this many frames, used by this many launches since (0: none)
+        uint32_t planFrames = 0, planUses = 0;
+        size_t planGrid = 0;
         // finished samples of one launch, 36 B per (sample, pixel); resolved into the images after the launch
         DeviceBuffer dSamples;
         hipStream_t stream = nullptr;    // traces of overlapping calls
@@ -155,6 +158,7 @@ struct pt_ctx {
     uint64_t forkCount = 0;
     bool forkDirty = true;
     bool tileOrdering = true;
+    int planEvery = 8;   // calls of at most 8 frames re-plan on every planEvery-th launch of a lane and reuse the list in between
     int tileSplit = -1;  // no block may cost more than 1/tileSplit of the launch's lower bound (0: never split, -1: by image size)
     uint32_t computeUnits = 256;
     std::vector<std::pair<void (*)(DevParams, DevScene, Images, DevCounters*), uint32_t>> residentWaves;  // per trace kernel variant
@@ -208,7 +212,7 @@ struct DeviceGuard {
 
 void forgetTileCosts(pt_ctx* c)
 {
-    for (pt_ctx::LaunchLane& L : c->lane) L.tileCostValid = false;
+    for (pt_ctx::LaunchLane& L : c->lane) L.tileCostValid = false, L.planFrames = 0;
 }
 
 float4* imagePtr(pt_ctx* c, int which) { return c->bound[which] ? c->bound[which] : (float4*)c->dImages[which].ptr; }
@@ -690,6 +694,7 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
                                                      (uint32_t*)L.dBlockStart.ptr, (int)tiles, st));
             HIP_TRY(L.dScanTemp.ensure(L.scanBytes));
             if (L.tileCostTiles != tiles) L.tileCostValid = false;
+            L.planFrames = 0;
             L.tileCostTiles = tiles;
             L.blockCapacity = capacity;
         }
@@ -701,7 +706,16 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
         P.blockList = nullptr;
         P.blockCount = nullptr;
         size_t gridBlocks = tiles;
-        if (L.tileCostValid && c->tileOrdering) {
+        // A short call (the viewer's pattern: a frame or a few per call) is a fifth planning: the list of the lane's
+        // last plan serves the next planEvery - 1 launches of the same frame count as it stands.
+        const bool reuse = L.tileCostValid && c->tileOrdering && frameCount <= 8u && L.planFrames == frameCount &&
+                           L.planUses < (uint32_t)std::max(1, c->planEvery);
+        if (reuse) {
+            L.planUses++;
+            P.blockList = (const unsigned int*)L.dBlockList.ptr;
+            P.blockCount = (const unsigned int*)L.dBlockCount.ptr;
+            gridBlocks = L.planGrid;
+        } else if (L.tileCostValid && c->tileOrdering) {
             // at least four samples per item, at most 255 items per tile
             const unsigned maxParts = split == 0 ? 1u : std::max(1u, std::min(255u, frameCount / 4u));
             const unsigned tb = 256, tg = (unsigned)((tiles + tb - 1) / tb);
@@ -722,6 +736,9 @@ int dispatchImpl(pt_ctx* c, uint32_t frameFirst, uint32_t frameCount, uint32_t f
             P.blockList = (const unsigned int*)L.dBlockList.ptr;
             P.blockCount = (const unsigned int*)L.dBlockCount.ptr;
             gridBlocks = split == 0 ? tiles : capacity;  // the most items the list can hold (blocks past its end find none)
+            L.planFrames = frameCount;
+            L.planUses = 1;
+            L.planGrid = gridBlocks;
         }
         // The items are pulled by a grid of as many waves as the chip keeps resident (a block per item spends the end
         // of its life with idle lanes, and a launch of few samples per pixel is nothing but such ends: 1080p, benchmark
@@ -1611,6 +1628,10 @@ int pt_debug_set_tuning(pt_ctx* c, int key, int value)
     case 13:
         if (value < 0 || value > kLbvhLeafLimit) return fail(PT_ERR_INVALID, "triangles per leaf must be 0 (by scene size) or 1..4");
         c->bvhLeafMax = value;
+        return PT_OK;
+    case 15:
+        if (value < 1 || value > 1024) return fail(PT_ERR_INVALID, "launches per plan must be 1..1024");
+        c->planEvery = value;
         return PT_OK;
     case 14:
         if (value < 0 || value > 4095) return fail(PT_ERR_INVALID, "decoded-texture budget must be 0..4095 MiB");
