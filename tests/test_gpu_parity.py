@@ -710,6 +710,31 @@ def test_four_wave_kernel_and_scheduler_thresholds_give_the_same_image():
             assert images[name][k].tobytes() == images["default"][k].tobytes(), (name, k)
 
 
+@pytest.mark.parametrize("tuning", [dict(), dict(plan_every=1, overlap_share=0), dict(plan_every=3, overlap_share=3),
+                                    dict(plan_every=1024, overlap_share=64), dict(plan_every=8, overlap_share=2, tile_split=4)],
+                         ids=["defaults", "plan-every-call-all-slots", "every-third-third-of-slots", "one-plan-few-waves", "split-tiles"])
+def test_short_calls_reusing_a_plan_on_a_share_of_the_waves(tuning):
+    """Calls of one or two frames reuse their launch lane's item list for some launches and start a share of the
+    resident waves each: neither may move a bit.  40 frames in one- and two-frame calls, with a change of frames per
+    call (a list made for one frame per call must not serve a two-frame call), against the oracle's 40 frames."""
+    w, h = 136, 88
+    o, g = _pair("TorusMixed", w, h)
+    p = R.default_params(w, h)
+    p.max_bounces = 4
+    g.set_params(p)
+    g.set_tuning(**tuning)
+    g.clear()
+    f = 1
+    for n in [1] * 14 + [2] * 7 + [1] * 6 + [2] * 3:
+        g.dispatch(f, n, 1)
+        f += n
+    assert f == 41
+    gpu = [g.read_image(k) for k in range(3)]
+    cpu = o.render(p, w, h, 1, 40, 1)
+    _assert_images_equal(gpu, cpu[:3], cpu[3], "40 frames in calls of one and two")
+    assert g.stats().samples == w * h * 2  # the last call's
+
+
 def test_overlapping_calls_keep_frame_order_and_the_last_calls_counters():
     """Dispatch calls of few frames trace on streams of their own, two or three calls in flight at a time,
     and only their resolve passes are ordered.  A run of one-frame calls, interleaved with the calls that
