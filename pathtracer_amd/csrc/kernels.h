@@ -376,11 +376,12 @@ PT_DEV int queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc, 
         // the rest half ordered (the larger of each first pair behind the smaller); finishing the sorting network
         // (two more comparators) visits no fewer nodes and costs 2 % on the reference's tree.  A push that is not one
         // writes the row above the stack's top, which nothing reads.
-        // (an empty slot has reference 0 and an inverted box; should a degenerate grid let a ray into it all the
-        // same, it must not pose as the nearest child: the keys go by the references)
+        // (an empty slot has reference 0 and an inverted box, which no ray enters; should a degenerate grid let one in
+        // all the same, the slot sorts by its distance like a child, and a reference of 0 in front only means that the
+        // step pops -- the children entered are on the stack by then, nothing is skipped)
         h0 &= hasNode, h1 &= hasNode, h2 &= hasNode, h3 &= hasNode;
         int r0 = h0 ? kids.x : 0, r1 = h1 ? kids.y : 0, r2 = h2 ? kids.z : 0, r3 = h3 ? kids.w : 0;
-        float k0 = r0 != 0 ? d0 : kFltMax, k1 = r1 != 0 ? d1 : kFltMax, k2 = r2 != 0 ? d2 : kFltMax, k3 = r3 != 0 ? d3 : kFltMax;
+        float k0 = h0 ? d0 : kFltMax, k1 = h1 ? d1 : kFltMax, k2 = h2 ? d2 : kFltMax, k3 = h3 ? d3 : kFltMax;
 #define PT_CSWAP(ka, ra, kb, rb)       \
     {                                  \
         const bool sw = kb < ka;       \
