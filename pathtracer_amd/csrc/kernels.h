@@ -382,15 +382,15 @@ PT_DEV int queryStep(const DevScene& S, Query& q, int* stack, StepCounters& sc, 
         h0 &= hasNode, h1 &= hasNode, h2 &= hasNode, h3 &= hasNode;
         int r0 = h0 ? kids.x : 0, r1 = h1 ? kids.y : 0, r2 = h2 ? kids.z : 0, r3 = h3 ? kids.w : 0;
         float k0 = h0 ? d0 : kFltMax, k1 = h1 ? d1 : kFltMax, k2 = h2 ? d2 : kFltMax, k3 = h3 ? d3 : kFltMax;
-#define PT_CSWAP(ka, ra, kb, rb)       \
-    {                                  \
-        const bool sw = kb < ka;       \
-        const float kt = sw ? kb : ka; \
-        const int rt = sw ? rb : ra;   \
-        kb = sw ? ka : kb;             \
-        rb = sw ? ra : rb;             \
-        ka = kt;                       \
-        ra = rt;                       \
+#define PT_CSWAP(ka, ra, kb, rb)          \
+    {                                     \
+        const bool sw = kb < ka;          \
+        const float kt = fmin_(ka, kb);   \
+        const int rt = sw ? rb : ra;      \
+        kb = fmax_(ka, kb);               \
+        rb = sw ? ra : rb;                \
+        ka = kt;                          \
+        ra = rt;                          \
     }
         PT_CSWAP(k0, r0, k1, r1)
         PT_CSWAP(k2, r2, k3, r3)
