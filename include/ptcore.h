@@ -370,8 +370,8 @@ int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, 
  * triangles per leaf, 1..4 (default 0: 2 for scenes of up to 1.3 M triangles, which the caches hold, 4 above);
  * 14: 8-bit textures are kept on the device as decoded floats (four per texel: a bilinear tap is one 16-byte read) while
  * all of them together fit in this many MiB, and as 8-bit words with a decode table beyond (default 256; 0 = never
- * decode).  Either form gives the same bits; 15: calls of at most 8 frames make a new launch plan on every value-th launch
- * of a launch lane and reuse the item list in between (default 8; 1 = plan every launch); 16: a call whose trace overlaps
+ * decode).  Either form gives the same bits; 15: a launch lane makes a new launch plan on every value-th launch
+ * and reuses the item list for the launches of the same frame count in between (default 8; 1 = plan every launch); 16: a call whose trace overlaps
  * its neighbours' launches 1/value of the waves the chip keeps resident (0 = all of them; -1, the default: half for calls of
  * one or two frames, all otherwise): the calls in flight fill the chip together, and each wave lives through more work
  * items before its last one ends in idle lanes. */
