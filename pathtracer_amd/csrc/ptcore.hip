@@ -18,7 +18,7 @@
 #include "host.h"
 #include "kernels.h"
 #include "lbvh.h"
-#include "ploc.h"
+#include "reinsert.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -169,6 +169,8 @@ struct pt_ctx {
     bool rebuildOnUpload = true;  // pt_upload_nodes' tree is checked, then replaced by the device builder's over the same primitives
     bool builderChosen = false;   // the tree on record comes from pt_process_buffers / _full_sweep: the caller named its builder, it stays
     int bvhLeafMax = 0;   // device BVH builder: most triangles per leaf (0: by scene size)
+    int bvhOptimise = -1;  // device BVH builder: reinsertion passes over the clustered tree (reinsert.h; 0: none, -1: by scene size)
+    int bvhOptimiseMod = 2;  // ... every how-manyth node is a candidate in a pass (the offset advances pass by pass)
     size_t textureDecodeBytes = 256u << 20;  // 8-bit textures are kept as decoded floats while they fit in this many bytes in all (the Infinity Cache's size)
     int plocRadius = 32;  // device BVH builder: neighbours searched on either side per clustering round (0: Morton radix tree)
     bool pullItems = true;  // megakernel: resident waves pull the work items (else one block per item)
@@ -1638,6 +1640,14 @@ int pt_debug_set_tuning(pt_ctx* c, int key, int value)
         if (value < 0 || value > kLbvhLeafLimit) return fail(PT_ERR_INVALID, "triangles per leaf must be 0 (by scene size) or 1..4");
         c->bvhLeafMax = value;
         return PT_OK;
+    case 17:
+        if (value < -1 || value > 256) return fail(PT_ERR_INVALID, "reinsertion passes must be -1 (by scene size) or 0..256");
+        c->bvhOptimise = value;
+        return PT_OK;
+    case 18:
+        if (value < 1 || value > 64) return fail(PT_ERR_INVALID, "candidate spacing must be 1..64");
+        c->bvhOptimiseMod = value;
+        return PT_OK;
     case 16:
         if (value < -1 || value > 64) return fail(PT_ERR_INVALID, "share of the wave slots must be -1 (by frame count), 0 (all) or 1/1..1/64");
         c->overlapShare = value;
@@ -1842,10 +1852,99 @@ int buildPlocTopology(pt_ctx* c, LbvhScratch& w, const RefPrimitiveAlign* dIn, i
         std::swap(boxIn, boxOut);
     }
     if (created != n - 1) return fail(PT_ERR_DEVICE, "clustering builder lost nodes (internal error)");
-    HIP_TRY(hipMemsetAsync((int*)w.pPosition.ptr + (n + n - 2), 0, 4, st));  // the root's triangles start at 0
-    HIP_TRY(hipMemsetAsync((int*)w.pPreorder.ptr + (n + n - 2), 0, 4, st));  // and the root is the first kept node
-    for (size_t r = rounds.size(); r-- > 0;)
-        hipLaunchKernelGGL(plocPositionKernel, grid((size_t)rounds[r].second), block, 0, st, rounds[r].first, rounds[r].second, n, N);
+    // Reinsertion passes: 16 by default, which is where the trees of the benchmark scenes stop getting better (a ray of the
+    // 576 k-triangle scene visits 3.53 nodes instead of 3.79, from inside the mesh 17.6 instead of 20.2; the build takes
+    // 34 ms instead of 20), 8 beyond four million triangles, where a pass takes 25 ms and more (20 M triangles: 12.4
+    // visits instead of 13.8, 0.34 s instead of 0.11 s).
+    const int optimisePasses = c->bvhOptimise >= 0 ? c->bvhOptimise : (count > 4000000 ? 8 : 16);
+    if (optimisePasses > 0 && n >= 8) {
+        // Reinsertion passes (reinsert.h) over the finished topology; the nodes are then no longer numbered level by
+        // level, so positions and depth-first ranks come from each node's path to the root.
+        // The passes' arrays live in buffers the clustering rounds are done with: parent links in `flags`, a move's
+        // destination in `scan`, gains and lock words in one cluster-box array, "is moving" words and old places in
+        // the other, the refit's counters in `nearest` and the two cluster-id arrays, a copy of the child links as they
+        // were in the unsorted key array.
+        const size_t total = 2 * count - 1;
+        int* rParent = (int*)w.flags.ptr;
+        int* rOut = (int*)w.scan.ptr;
+        float* rGain = (float*)w.boxA.ptr;
+        unsigned long long* rLock = (unsigned long long*)((char*)w.boxA.ptr + count * 8);
+        unsigned long long* rMoving = (unsigned long long*)w.boxB.ptr;
+        int* rOld = (int*)((char*)w.boxB.ptr + count * 16);
+        unsigned int* rVisits = (unsigned int*)w.nearest.ptr;
+        unsigned int* rDirty = (unsigned int*)w.idA.ptr;
+        unsigned int* rPending = (unsigned int*)w.idB.ptr;  // (the refit's stamps)
+        int* rLeft0 = (int*)w.keys.ptr;
+        int* rRight0 = (int*)((char*)w.keys.ptr + count * 4);
+        ReinsertTree R{rParent, N.left, N.right, N.box, n};
+        HIP_TRY(hipMemcpyAsync(rLeft0, N.left, internal * 4, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(rRight0, N.right, internal * 4, hipMemcpyDeviceToDevice, st));
+        auto refit = [&]() -> int {
+            HIP_TRY(hipMemsetAsync(rVisits, 0, internal * 4, st));
+            hipLaunchKernelGGL(reinsertRefitKernel, grid(count), block, 0, st, R, N, rVisits);
+            HIP_TRY(hipGetLastError());
+            return PT_OK;
+        };
+        hipLaunchKernelGGL(reinsertParentKernel, grid(internal), block, 0, st, R);
+        const int mod = std::max(1, c->bvhOptimiseMod);
+        // moves applied per pass, counted in the array the relabelling fills afterwards; read back once every candidate
+        // has had its turn (`mod` passes): a round without a move ends the passes
+        unsigned int* rMoves = (unsigned int*)w.packedAt.ptr;
+        const int passes = std::min(optimisePasses, (int)std::min<size_t>(internal, 256));
+        HIP_TRY(hipMemsetAsync(rMoves, 0, (size_t)passes * 4, st));
+        std::vector<unsigned int> moves((size_t)passes, 0u);
+        int heightNow = 0;
+        HIP_TRY(hipMemcpyAsync(&heightNow, N.height + (n - 2), 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int pass = 0; pass < passes; pass++) {
+            HIP_TRY(hipMemsetAsync(rLock, 0, total * 8, st));
+            HIP_TRY(hipMemsetAsync(rMoving, 0, total * 8, st));
+            HIP_TRY(hipMemsetAsync(rOut, 0xff, total * 4, st));  // "stays where it is"
+            // (blocks of one wave: the searches of a block's lanes differ widely in length)
+            hipLaunchKernelGGL(reinsertSearchKernel, dim3((unsigned int)((total + 63) / 64)), dim3(64), 0, st, R, mod, pass % mod, rOut, rGain, rLock);
+            hipLaunchKernelGGL(reinsertClaimKernel, grid(total), block, 0, st, R, rOut, (const float*)rGain,
+                               (const unsigned long long*)rLock, rMoving);
+            hipLaunchKernelGGL(reinsertRingKernel, grid(total), block, 0, st, R, rOut, (const unsigned long long*)rMoving);
+            hipLaunchKernelGGL(reinsertApplyKernel, grid(total), block, 0, st, R, (const int*)rOut, rOld, rMoves + pass);
+            // boxes, counts and heights above the moves' old and new places (the rest of the tree has not changed)
+            HIP_TRY(hipMemsetAsync(rDirty, 0, internal * 4, st));
+            HIP_TRY(hipMemsetAsync(rPending, 0, internal * 4, st));
+            hipLaunchKernelGGL(reinsertMarkKernel, grid(total), block, 0, st, R, (const int*)rOut, (const int*)rOld, rDirty);
+            // one launch per level of flagged nodes; the root's stamp says when the refit is complete (the tree's height,
+            // known from the pass before, is how many launches that takes unless the pass made the tree deeper)
+            unsigned int round = 0, rootStamp = 0;
+            for (;;) {
+                for (int k = 0; k < heightNow + 2; k++)
+                    hipLaunchKernelGGL(reinsertRefitMarkedKernel, grid(internal), block, 0, st, R, N, (const unsigned int*)rDirty, rPending, round++);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(&moves[(size_t)pass], rMoves + pass, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(&rootStamp, rPending + (n - 2), 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(&heightNow, N.height + (n - 2), 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                if (moves[(size_t)pass] == 0u || rootStamp != 0u) break;
+                if (round > 4096u) return fail(PT_ERR_DEVICE, "tree optimisation: the refit does not end (internal error)");
+            }
+            if ((pass + 1) % mod == 0) {  // a round of passes in which every candidate had its turn and none moved: done
+                unsigned int sum = 0;
+                for (int k = pass + 1 - mod; k <= pass; k++) sum += moves[(size_t)k];
+                if (sum == 0u) break;
+            }
+        }
+        if (heightNow > 60) {  // deeper than the traversal takes: the clustered tree as it was
+            HIP_TRY(hipMemcpyAsync(N.left, rLeft0, internal * 4, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(N.right, rRight0, internal * 4, hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(reinsertParentKernel, grid(internal), block, 0, st, R);
+            const int rc = refit();
+            if (rc != PT_OK) return rc;
+        }
+        hipLaunchKernelGGL(reinsertPlaceKernel, grid(total), block, 0, st, R, N);
+        HIP_TRY(hipGetLastError());
+    } else {
+        HIP_TRY(hipMemsetAsync((int*)w.pPosition.ptr + (n + n - 2), 0, 4, st));  // the root's triangles start at 0
+        HIP_TRY(hipMemsetAsync((int*)w.pPreorder.ptr + (n + n - 2), 0, 4, st));  // and the root is the first kept node
+        for (size_t r = rounds.size(); r-- > 0;)
+            hipLaunchKernelGGL(plocPositionKernel, grid((size_t)rounds[r].second), block, 0, st, rounds[r].first, rounds[r].second, n, N);
+    }
     hipLaunchKernelGGL(plocRelabelKernel, grid(count), block, 0, st, n, N, (const unsigned int*)w.order.ptr,
                        (unsigned int*)w.finalOrder.ptr, T, (unsigned int*)w.packedAt.ptr);
     HIP_TRY(hipGetLastError());
