@@ -23,6 +23,7 @@ ap.add_argument("--copies", type=int, default=1)
 ap.add_argument("--spp", type=int, default=16)
 ap.add_argument("--check", action="store_true", help="walk the downloaded tree on the host (slow beyond a million triangles)")
 ap.add_argument("--cost", action="store_true", help="surface-area cost of the downloaded tree")
+ap.add_argument("--tuning", default="", help="other tuning settings for every build, key=value,key=value")
 ap.add_argument("--width", type=int, default=0)
 ap.add_argument("--height", type=int, default=0)
 a = ap.parse_args()
@@ -47,6 +48,10 @@ if a.scene == "dragonglass" and a.copies == 1:
     views.append(("close-up", p2))
 print(f"{a.scene}: {source.shape[0]} triangles, {W}x{H}, {a.spp} spp per launch", flush=True)
 g = R.Renderer(W, H)
+for slot, texels, srgb in work.get("textures", []):
+    g.upload_texture(slot, texels, srgb)
+if a.tuning:
+    g.set_tuning(**{k: int(v) for k, v in (item.split("=") for item in a.tuning.split(","))})
 g.build_bvh_device(source[:1000])  # warm-up: module load, hipcub's first use
 for setting in a.settings:
     passes, mod = (int(x) for x in setting.split(":"))

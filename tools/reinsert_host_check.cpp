@@ -1,6 +1,6 @@
 // The reinsertion passes of the device builder (pathtracer_amd/csrc/reinsert.h) run thread by thread on the host over
 // random triangle boxes, with the tree checked after every pass: links consistent, every node reached from the root
-// exactly once, boxes the unions of their children's, summed area not rising.  Build and run (AddressSanitizer on):
+// exactly once, boxes the unions of their children's.  Build and run (AddressSanitizer on):
 //   g++ -O1 -g -std=c++17 -fsanitize=address,undefined -Itools/hostshim -Ipathtracer_amd/csrc tools/reinsert_host_check.cpp -o /tmp/reinsert_check && /tmp/reinsert_check
 #include <cstdio>
 #include <cstdlib>
