@@ -374,7 +374,12 @@ int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, 
  * and reuses the item list for the launches of the same frame count in between (default 8; 1 = plan every launch); 16: a call whose trace overlaps
  * its neighbours' launches 1/value of the waves the chip keeps resident (0 = all of them; -1, the default: half for calls of
  * one or two frames, all otherwise): the calls in flight fill the chip together, and each wave lives through more work
- * items before its last one ends in idle lanes. */
+ * items before its last one ends in idle lanes; 17: device BVH builder: reinsertion passes over the clustered tree,
+ * 0..256 (default -1: 16, and 8 for scenes of more than four million triangles; 0 = the clustered tree as built) -- in a
+ * pass every candidate node looks for the place in the tree where it, moved there with its parent, lowers the summed
+ * surface area most, and the moves that do not touch each other's nodes are made; 18: every value-th node is a candidate
+ * in a pass, the offset advancing pass by pass (default 2).  Trees differ between settings, images only where two
+ * triangles are hit at exactly the same distance. */
 int pt_debug_set_tuning(pt_ctx* ctx, int key, int value);
 
 /* Profiling hook, not part of the drop-in surface (no counterpart in the reference): wave-level
