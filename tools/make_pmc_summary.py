@@ -66,10 +66,13 @@ def main(src, dst, shape):
     # What limits the kernel.  (l1_busy + l1_stall is 1 whatever the kernel does -- stall cycles fill the cycles without an
     # access -- so the pair says nothing about the bound; probes with extra instructions and extra reads per node visit
     # show both the vector pipe and the L1 with slack: profiles/r03_bound_experiment.txt.)  A launch that moves more than
-    # half of the HBM peak through the fabric is called memory bound; otherwise a wave's serial chain of one memory round
-    # trip and a few hundred vector instructions per traversal step, with the two other waves of its SIMD to cover it.
+    # 4.8 TB/s through the fabric -- 0.6 of the HBM peak, 85 % of the 5.5-5.8 TB/s at which random rows of a buffer far
+    # larger than the Infinity Cache can be gathered -- is called memory bound (the 20 M-triangle launch: 5.2 TB/s);
+    # otherwise (the cache-resident scenes: 1.9-4.0 TB/s out of an Infinity Cache that delivers 8.6) it is a wave's serial
+    # chain of one memory round trip and a few hundred vector instructions per traversal step, with the two other waves
+    # of its SIMD to cover it.
     out["bound"] = "hbm"
-    out["limited_by"] = ("fabric / HBM bandwidth" if traffic / (k["avg_ns"] / 1e9) / 1e9 > 4000.0 else
+    out["limited_by"] = ("fabric / HBM bandwidth" if traffic / (k["avg_ns"] / 1e9) / 1e9 > 4800.0 else
                          "latency and issue at 3 waves per SIMD (registers and LDS cap the occupancy)")
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
