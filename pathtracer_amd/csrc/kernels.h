@@ -458,25 +458,37 @@ struct BounceRays {
 };
 
 // Primary ray: pathtracing.comp:150-200 (inverse(ViewMatrix) arrives precomputed in P.invView).
-PT_DEV void mulMat4(const float* M, float x, float y, float z, float w, float out[4])
+template <class Matrix>
+PT_DEV void mulMat4(Matrix M, float x, float y, float z, float w, float out[4])
 {
     for (int i = 0; i < 4; i++) out[i] = ((M[0 + i] * x + M[4 + i] * y) + M[8 + i] * z) + M[12 + i] * w;
 }
-PT_DEV void pinholeRay(const DevParams& P, float u, float v, v3& ro, v3& rd)
+// The kernel's argument segment as floats (DevParams is every kernel's first argument: invView at float 0, invProj at 16).
+// The persistent kernel reads the two camera matrices from there, through a pointer made opaque where a sample starts, so
+// that they are fetched by scalar loads at that point instead of living in (spilled) scalar registers across the loop.
+typedef const __attribute__((address_space(4))) float* KernargFloats;
+static_assert(offsetof(DevParams, invView) == 0 && offsetof(DevParams, invProj) == 64, "KernargFloats offsets below");
+PT_DEV void pinholeRay(const DevParams& P, float u, float v, v3& ro, v3& rd, KernargFloats K = nullptr)
 {
     float vp[4];
-    mulMat4(P.invProj, u * 2.0f - 1.0f, v * 2.0f - 1.0f, 0.0f, 1.0f, vp);
+    if (K) mulMat4(K + 16, u * 2.0f - 1.0f, v * 2.0f - 1.0f, 0.0f, 1.0f, vp);
+    else mulMat4(P.invProj, u * 2.0f - 1.0f, v * 2.0f - 1.0f, 0.0f, 1.0f, vp);
     v3 origin = mk3(vp[0], vp[1], vp[2]) / vp[3];
     v3 direction = normalize3(origin);
     float o4[4], d4[4];
-    mulMat4(P.invView, origin.x, origin.y, origin.z, 1.0f, o4);
-    mulMat4(P.invView, direction.x, direction.y, direction.z, 0.0f, d4);
+    if (K) {
+        mulMat4(K, origin.x, origin.y, origin.z, 1.0f, o4);
+        mulMat4(K, direction.x, direction.y, direction.z, 0.0f, d4);
+    } else {
+        mulMat4(P.invView, origin.x, origin.y, origin.z, 1.0f, o4);
+        mulMat4(P.invView, direction.x, direction.y, direction.z, 0.0f, d4);
+    }
     ro = mk3(o4[0], o4[1], o4[2]);
     rd = mk3(d4[0], d4[1], d4[2]);
 }
-PT_DEV void primaryRay(const DevParams& P, float u, float v, unsigned& rng, v3& ro, v3& rd)
+PT_DEV void primaryRay(const DevParams& P, float u, float v, unsigned& rng, v3& ro, v3& rd, KernargFloats K = nullptr)
 {
-    pinholeRay(P, u, v, ro, rd);
+    pinholeRay(P, u, v, ro, rd, K);
     if (P.apertureSize != 0.0f) {  // thin lens (:166-187)
         const float* VM = P.view;
         v3 cameraForward = -mk3(VM[8], VM[9], VM[10]);
@@ -494,7 +506,7 @@ PT_DEV void primaryRay(const DevParams& P, float u, float v, unsigned& rng, v3& 
 }
 
 // main(): pathtracing.comp:206-245 for sample index ps.k of pixel (px, py).
-PT_DEV void startSample(const DevParams& P, unsigned px, unsigned py, PathState& ps, v3& ro, v3& rd)
+PT_DEV void startSample(const DevParams& P, unsigned px, unsigned py, PathState& ps, v3& ro, v3& rd, KernargFloats K = nullptr)
 {
     const unsigned pixelIndex = py * (unsigned)P.frameW + px;  // uint(FrameDimensions.x), :213
     ps.frame = P.frameFirst + ps.k * P.frameStride;
@@ -506,7 +518,7 @@ PT_DEV void startSample(const DevParams& P, unsigned px, unsigned py, PathState&
         u = u + (r1 - 0.5f) / P.frameW;
         v = v + (r2 - 0.5f) / P.frameH;
     }
-    primaryRay(P, u, v, ps.rng, ro, rd);
+    primaryRay(P, u, v, ps.rng, ro, rd, K);
     ps.radiance = splat(0.0f);
     ps.throughput = splat(1.0f);
     ps.f = splat(1.0f);
@@ -985,7 +997,12 @@ __global__ __launch_bounds__(kMegaThreads, WAVES) void renderKernel(DevParams P,
                 const unsigned inTile = s_pixel[slot];
                 pixel = tileOrigin + ((inTile & 7u) | ((inTile >> 3) << 16));
                 v3 ro, rd;
-                startSample(P, pixel & 0xffffu, pixel >> 16, ps, ro, rd);
+                // (the camera matrices by scalar loads from the argument segment, here: held in scalar registers across the
+                // loop they are 32 of the 52 values the kernel spilled to vector lanes, and a sample's start read them
+                // back one v_readlane each; 0.6 % of the launch on every scene)
+                KernargFloats K = (KernargFloats)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(K));
+                startSample(P, pixel & 0xffffu, pixel >> 16, ps, ro, rd, K);
                 hasExt = false;
                 nSamples++;
                 nRays++;
