@@ -378,8 +378,9 @@ int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, 
  * 0..256 (default -1: 16, and 8 for scenes of more than four million triangles; 0 = the clustered tree as built) -- in a
  * pass every candidate node looks for the place in the tree where it, moved there with its parent, lowers the summed
  * surface area most, and the moves that do not touch each other's nodes are made; 18: every value-th node is a candidate
- * in a pass, the offset advancing pass by pass (default 2).  Trees differ between settings, images only where two
- * triangles are hit at exactly the same distance. */
+ * in a pass, the offset advancing pass by pass (default 2); 19: a tree that the passes left more than this many levels
+ * deep is put back as the clustering built it (default 60, the most the traversal takes with room to spare).  Trees
+ * differ between settings, images only where two triangles are hit at exactly the same distance. */
 int pt_debug_set_tuning(pt_ctx* ctx, int key, int value);
 
 /* Profiling hook, not part of the drop-in surface (no counterpart in the reference): wave-level

@@ -170,6 +170,7 @@ struct pt_ctx {
     bool builderChosen = false;   // the tree on record comes from pt_process_buffers / _full_sweep: the caller named its builder, it stays
     int bvhLeafMax = 0;   // device BVH builder: most triangles per leaf (0: by scene size)
     int bvhOptimise = -1;  // device BVH builder: reinsertion passes over the clustered tree (reinsert.h; 0: none, -1: by scene size)
+    int bvhOptimiseMaxHeight = 60;  // ... a tree the passes left deeper than this is put back as the clustering built it
     int bvhOptimiseMod = 2;  // ... every how-manyth node is a candidate in a pass (the offset advances pass by pass)
     size_t textureDecodeBytes = 256u << 20;  // 8-bit textures are kept as decoded floats while they fit in this many bytes in all (the Infinity Cache's size)
     int plocRadius = 32;  // device BVH builder: neighbours searched on either side per clustering round (0: Morton radix tree)
@@ -1644,6 +1645,10 @@ int pt_debug_set_tuning(pt_ctx* c, int key, int value)
         if (value < -1 || value > 256) return fail(PT_ERR_INVALID, "reinsertion passes must be -1 (by scene size) or 0..256");
         c->bvhOptimise = value;
         return PT_OK;
+    case 19:
+        if (value < 1 || value > 60) return fail(PT_ERR_INVALID, "height limit of the optimised tree must be 1..60");
+        c->bvhOptimiseMaxHeight = value;
+        return PT_OK;
     case 18:
         if (value < 1 || value > 64) return fail(PT_ERR_INVALID, "candidate spacing must be 1..64");
         c->bvhOptimiseMod = value;
@@ -1930,7 +1935,7 @@ int buildPlocTopology(pt_ctx* c, LbvhScratch& w, const RefPrimitiveAlign* dIn, i
                 if (sum == 0u) break;
             }
         }
-        if (heightNow > 60) {  // deeper than the traversal takes: the clustered tree as it was
+        if (heightNow > c->bvhOptimiseMaxHeight) {  // deeper than the traversal takes: the clustered tree as it was
             HIP_TRY(hipMemcpyAsync(N.left, rLeft0, internal * 4, hipMemcpyDeviceToDevice, st));
             HIP_TRY(hipMemcpyAsync(N.right, rRight0, internal * 4, hipMemcpyDeviceToDevice, st));
             hipLaunchKernelGGL(reinsertParentKernel, grid(internal), block, 0, st, R);

@@ -259,3 +259,19 @@ def test_reinsertion_passes_lower_the_cost_and_the_visits_and_repeat_exactly():
     assert cost[16] < cost[0] and visits[16] < visits[0]
     differing = int(np.any(images[0].view(np.uint32) != images[16].view(np.uint32), axis=-1).sum())
     assert differing <= 1e-4 * width * height, differing  # (the closest hit does not depend on the tree unless distances tie)
+
+
+def test_a_tree_the_passes_left_too_deep_is_put_back_as_built():
+    """With the height limit of the optimised tree below any real tree's height the builder falls back to the clustered
+    tree as it was before the passes: byte for byte the tree of a build without passes."""
+    prims100, _ = soup(scenes.recipe("TorusMixed"))
+    source = R.align_primitives(prims100)
+    trees = []
+    for tuning in (dict(bvh_optimise=0), dict(bvh_optimise=16, bvh_optimise_max_height=1)):
+        g = R.Renderer(32, 32)
+        g.set_tuning(**tuning)
+        g.build_bvh_device(source)
+        nodes, prims = g.download_bvh()
+        _check_tree(nodes, prims, source)
+        trees.append((nodes.tobytes(), prims.tobytes()))
+    assert trees[0] == trees[1]
