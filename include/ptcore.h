@@ -367,7 +367,7 @@ int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, 
  * of consecutive pt_dispatch calls may overlap, the next call's waves filling the chip while the last waves of
  * the call before run dry (1), never do (0), or do for calls of at most 8 frames (-1, the default); calls
  * overlap on the library's own stream only, never on one set with pt_set_stream; 13: device BVH builder: most
- * triangles per leaf, 1..4 (default 0: 2 for scenes of up to 1.3 M triangles, which the caches hold, 4 above);
+ * triangles per leaf, 1..4 (default 0: 2 for scenes of up to 8 M triangles, 3 above);
  * 14: 8-bit textures are kept on the device as decoded floats (four per texel: a bilinear tap is one 16-byte read) while
  * all of them together fit in this many MiB, and as 8-bit words with a decode table beyond (default 256; 0 = never
  * decode).  Either form gives the same bits; 15: a launch lane makes a new launch plan on every value-th launch

@@ -26,9 +26,10 @@
 namespace ptcore {
 
 // Most triangles a leaf of the device-built tree may hold (LbvhTree::leafMax, PlocNodes::leafMax), chosen per build:
-// 2 for scenes the caches hold (the triangle half of the traversal step runs at a third of the lanes: a cheap box more and
-// a triangle test fewer is 2-4 % faster on every such scene measured), the reference's 4 (BVH::BuildBvhWithSah is called
-// with leaf size 4, PathTracingRenderer.cpp:583) for scenes that stream from HBM, where the extra nodes cost more.
+// 2 for scenes of up to eight million triangles (the triangle half of the traversal step runs at a third of the lanes: a
+// cheap box more and a triangle test fewer is 2-4 % faster on every such scene measured), 3 for larger ones, which stream
+// from HBM and pay more for the extra nodes; never more than the reference's 4 (BVH::BuildBvhWithSah is called with leaf
+// size 4, PathTracingRenderer.cpp:583).
 constexpr int kLbvhLeafLimit = 4;
 
 struct LbvhBounds {

@@ -1572,7 +1572,7 @@ int pt_scene_bytes(pt_ctx* c, uint64_t* nodeBytes, uint64_t* triangleBytes, uint
 // builder: clustering search radius (0 = Morton radix tree); 11: megakernel compiled for 3 or 4 waves per SIMD
 // (0 = the default, 3); 12: the trace launches of consecutive dispatch calls may overlap (1), never do (0), or do for
 // calls of at most 8 frames (-1, the default); 13: device BVH builder: most triangles per leaf (1..4; 0, the default: 2 for
-// scenes of up to 1.3 M triangles, 4 above).
+// scenes of up to 8 M triangles, 3 above).
 #ifdef PT_EXPERIMENT_SHADE_TIMERS
 // Experiment builds only: the tick sums of shadeRay's sections since the last call (and resets them).
 extern "C" int pt_experiment_shade_ticks(unsigned long long* out8)
@@ -1973,10 +1973,11 @@ int buildLbvh(pt_ctx* c, const RefPrimitiveAlign* hostPrims, size_t count)
     const int n = (int)count;
     const unsigned int un = (unsigned int)count;
     const size_t internal = count > 1 ? count - 1 : 1;
-    // leaves of two triangles while the scene (about 200 bytes a triangle with its nodes) fits the 256 MB Infinity
-    // Cache, of four beyond: 20 M triangles at 3840 x 2160 are 2.6 % slower with two, every cache-resident scene
-    // 2-4 % faster
-    const int leafMax = c->bvhLeafMax > 0 ? c->bvhLeafMax : (count > 1300000 ? kLbvhLeafLimit : 2);
+    // leaves of two triangles up to eight million triangles, of three beyond.  On the trees the reinsertion passes leave,
+    // 1.3 M and 5.2 M triangles at 1920 x 1080 trace 2.9 % and 2.2 % faster with two than with four (2.5 % and 1.1 % faster
+    // than with three); 20 M triangles at 3840 x 2160, which stream from HBM (0.65 of its peak), trace 5 618 Mrays/s with
+    // three, 5 482 with four, 5 308 with two: there the extra nodes of small leaves cost more than the tests they save.
+    const int leafMax = c->bvhLeafMax > 0 ? c->bvhLeafMax : (count > 8000000 ? 3 : 2);
     LbvhScratch w;
     HIP_TRY(w.in.ensure(count * sizeof(RefPrimitiveAlign)));
     HIP_TRY(w.keys.ensure(count * 8));
