@@ -379,7 +379,11 @@ int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* triangle_bytes, 
  * pass every candidate node looks for the place in the tree where it, moved there with its parent, lowers the summed
  * surface area most, and the moves that do not touch each other's nodes are made; 18: every value-th node is a candidate
  * in a pass, the offset advancing pass by pass (default 2); 19: a tree that the passes left more than this many levels
- * deep is put back as the clustering built it (default 60, the most the traversal takes with room to spare).  Trees
+ * deep is put back as the clustering built it (default 60, the most the traversal takes with room to spare); 20: when a
+ * caller's tree is traversed as uploaded (pt_set_bvh_rebuild(ctx, 0), pt_process_buffers), its leaves of more than value
+ * triangles are cut into leaves of at most value, in place and in order, under new interior nodes with the tight boxes
+ * of the sub-ranges (default 0 = the caller's leaves as they are: cutting them to two gains 0.1-1.5 % on four of the
+ * benchmark scenes and loses 1.9 % on the interior; set before the upload).  Trees
  * differ between settings, images only where two triangles are hit at exactly the same distance. */
 int pt_debug_set_tuning(pt_ctx* ctx, int key, int value);
 

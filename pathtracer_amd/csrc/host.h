@@ -35,9 +35,11 @@ struct PackedScene {
     int32_t rootRef = 0;
     int maxDepth = 0;  // interior levels below (and including) the root; bounds the traversal stack
 };
-// Returns empty string on success, else a description of what is malformed.
+// Returns empty string on success, else a description of what is malformed.  leafCut > 0: a leaf of more triangles than
+// that is cut into a small sub-tree of leaves of at most leafCut (the triangles keep their order, the new boxes are the
+// tight boxes of the sub-ranges), so that the traversal, which tests one triangle per step, scans short leaves.
 std::string PackScene(const RefNodeAlign* nodes, size_t nodeCount, const RefPrimitiveAlign* prims,
-                      size_t primCount, size_t materialCount, PackedScene& out);
+                      size_t primCount, size_t materialCount, PackedScene& out, int leafCut = 0);
 std::string PackMaterials(const RefMaterialAlign* mats, size_t count, size_t textureSlots,
                           const std::vector<int>& slotToTexture, std::vector<DevMaterial>& out);
 

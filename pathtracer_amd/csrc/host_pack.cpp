@@ -7,8 +7,11 @@
 // (Shaders/Library/intersection.glsl:23-25,48) are evaluated once here with the same float
 // expressions, so the kernel's results stay bit-identical while it loads 48 B per test
 // instead of 112 B.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -29,7 +32,7 @@ constexpr int kMaxLeaf = 8;  // leaf reference encodes (count - 1) in 3 bits
 }  // namespace
 
 std::string PackScene(const RefNodeAlign* nodes, size_t nodeCount, const RefPrimitiveAlign* prims,
-                      size_t primCount, size_t materialCount, PackedScene& out)
+                      size_t primCount, size_t materialCount, PackedScene& out, int leafCut)
 {
     out = PackedScene{};
     if (nodeCount < 2) return "BVH needs at least the dummy node 0 and a root node 1";
@@ -93,8 +96,46 @@ std::string PackScene(const RefNodeAlign* nodes, size_t nodeCount, const RefPrim
         return ~(int32_t)(((uint32_t)n.index << 3) | (uint32_t)(n.n - 1));
     };
 
+    // A validated leaf range, cut into leaves of at most leafCut triangles when it holds more: returns the reference of
+    // the range (a leaf, or the interior node on top of its halves) and reports the levels it added.
+    auto rangeBox = [&](size_t first, size_t count, float lo[3], float hi[3]) {
+        for (int k = 0; k < 3; k++) lo[k] = std::numeric_limits<float>::max(), hi[k] = -std::numeric_limits<float>::max();
+        for (size_t i = first; i < first + count; i++)
+            for (int k = 0; k < 3; k++) {
+                lo[k] = std::min(lo[k], std::min(prims[i].posAuvX[k], std::min(prims[i].posBuvX[k], prims[i].posCuvX[k])));
+                hi[k] = std::max(hi[k], std::max(prims[i].posAuvX[k], std::max(prims[i].posBuvX[k], prims[i].posCuvX[k])));
+            }
+    };
+    std::function<int32_t(size_t, size_t, int&)> cutRange = [&](size_t first, size_t count, int& levels) -> int32_t {
+        if (leafCut <= 0 || count <= (size_t)leafCut) {
+            levels = 0;
+            return ~(int32_t)(((uint32_t)first << 3) | (uint32_t)(count - 1));
+        }
+        const size_t leftCount = (count + 1) / 2, rightCount = count - leftCount;
+        const int32_t at = (int32_t)out.nodes.size();
+        out.nodes.push_back(DevNode{});
+        int levelsL = 0, levelsR = 0;
+        DevNode d{};
+        rangeBox(first, leftCount, d.lmin, d.lmax);
+        rangeBox(first + leftCount, rightCount, d.rmin, d.rmax);
+        d.left = cutRange(first, leftCount, levelsL);
+        d.right = cutRange(first + leftCount, rightCount, levelsR);
+        out.nodes[(size_t)at] = d;
+        levels = 1 + std::max(levelsL, levelsR);
+        return at;
+    };
+
     std::string err;
     const RefNodeAlign& root = nodes[1];
+    if (root.n > 0 && leafCut > 0 && root.n > leafCut) {  // a root leaf that is cut becomes a small tree of its own
+        out.nodes.push_back(DevNode{});
+        (void)leafRef(root, 1, err);
+        if (!err.empty()) return err;
+        int levels = 0;
+        out.rootRef = cutRange((size_t)root.index, (size_t)root.n, levels);
+        out.maxDepth = levels;
+        return err;
+    }
     if (root.n > 0) {
         out.nodes.push_back(DevNode{});  // node 0 must exist: idle lanes fetch it
         out.rootRef = leafRef(root, 1, err);
@@ -133,6 +174,9 @@ std::string PackScene(const RefNodeAlign* nodes, size_t nodeCount, const RefPrim
             if (ch.n > 0) {
                 refs[c] = leafRef(ch, (size_t)child[c], err);
                 if (!err.empty()) return err;
+                int levels = 0;
+                refs[c] = cutRange((size_t)ch.index, (size_t)ch.n, levels);
+                if (it.depth + levels > out.maxDepth) out.maxDepth = it.depth + levels;
             } else {
                 refs[c] = (int32_t)out.nodes.size();
                 out.nodes.push_back(DevNode{});

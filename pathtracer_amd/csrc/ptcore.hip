@@ -169,6 +169,7 @@ struct pt_ctx {
     bool rebuildOnUpload = true;  // pt_upload_nodes' tree is checked, then replaced by the device builder's over the same primitives
     bool builderChosen = false;   // the tree on record comes from pt_process_buffers / _full_sweep: the caller named its builder, it stays
     int bvhLeafMax = 0;   // device BVH builder: most triangles per leaf (0: by scene size)
+    int leafRecut = 0;    // a traversed caller's tree: leaves of more triangles than this are cut into leaves of at most this many (0: kept)
     int bvhOptimise = -1;  // device BVH builder: reinsertion passes over the clustered tree (reinsert.h; 0: none, -1: by scene size)
     int bvhOptimiseMaxHeight = 60;  // ... a tree the passes left deeper than this is put back as the clustering built it
     int bvhOptimiseMod = 2;  // ... every how-manyth node is a candidate in a pass (the offset advances pass by pass)
@@ -294,8 +295,9 @@ int syncScene(pt_ctx* c)
                                       std::to_string(c->materials.size()) + " materials are uploaded");
     if (c->geometryDirty && !c->deviceGeometry) {
         PackedScene packed;
+        const bool rebuilt = c->rebuildOnUpload && !c->builderChosen;  // (then the uploaded tree is only validated here)
         std::string err = PackScene(c->nodes.data(), c->nodes.size(), c->prims.data(), c->prims.size(),
-                                    c->materials.size(), packed);
+                                    c->materials.size(), packed, rebuilt ? 0 : c->leafRecut);
         if (!err.empty()) return fail(PT_ERR_SCENE, err);
         if (c->rebuildOnUpload && !c->builderChosen) {
             // the uploaded tree was only validated; the device builder's tree over the same primitives is used
@@ -1644,6 +1646,10 @@ int pt_debug_set_tuning(pt_ctx* c, int key, int value)
     case 17:
         if (value < -1 || value > 256) return fail(PT_ERR_INVALID, "reinsertion passes must be -1 (by scene size) or 0..256");
         c->bvhOptimise = value;
+        return PT_OK;
+    case 20:
+        if (value < 0 || value > 8) return fail(PT_ERR_INVALID, "leaf re-cut must be 0 (keep the caller's leaves) or 1..8");
+        c->leafRecut = value;  // (takes effect at the next upload)
         return PT_OK;
     case 19:
         if (value < 1 || value > 60) return fail(PT_ERR_INVALID, "height limit of the optimised tree must be 1..60");

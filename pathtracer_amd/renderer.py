@@ -134,10 +134,10 @@ class Renderer:
         """pt_dispatch_static: the dispatch that allocates nothing (scratch in a static device array)."""
         check(self._lib.pt_dispatch_static(self._h, int(frame_first), int(frame_count), int(frame_stride)))
 
-    TUNING_KEYS = {"pipeline": 0, "trav_exit": 1, "refill_min": 2, "check_every": 3, "traverse_blocks": 4, "hit_min": 5, "tile_order": 6, "tile_split": 7, "sample_budget_mib": 8, "pull_items": 9, "ploc_radius": 10, "waves_per_simd": 11, "overlap_calls": 12, "bvh_leaf_max": 13, "texture_decode_mib": 14, "plan_every": 15, "overlap_share": 16, "bvh_optimise": 17, "bvh_optimise_mod": 18, "bvh_optimise_max_height": 19}
+    TUNING_KEYS = {"pipeline": 0, "trav_exit": 1, "refill_min": 2, "check_every": 3, "traverse_blocks": 4, "hit_min": 5, "tile_order": 6, "tile_split": 7, "sample_budget_mib": 8, "pull_items": 9, "ploc_radius": 10, "waves_per_simd": 11, "overlap_calls": 12, "bvh_leaf_max": 13, "texture_decode_mib": 14, "plan_every": 15, "overlap_share": 16, "bvh_optimise": 17, "bvh_optimise_mod": 18, "bvh_optimise_max_height": 19, "leaf_recut": 20}
 
     def set_tuning(self, **kw):
-        """pipeline=0|1 (megakernel|wavefront), trav_exit, refill_min, check_every, traverse_blocks, hit_min, tile_order, tile_split, sample_budget_mib, pull_items, ploc_radius, waves_per_simd, overlap_calls, bvh_leaf_max, texture_decode_mib, plan_every, overlap_share, bvh_optimise, bvh_optimise_mod, bvh_optimise_max_height."""
+        """pipeline=0|1 (megakernel|wavefront), trav_exit, refill_min, check_every, traverse_blocks, hit_min, tile_order, tile_split, sample_budget_mib, pull_items, ploc_radius, waves_per_simd, overlap_calls, bvh_leaf_max, texture_decode_mib, plan_every, overlap_share, bvh_optimise, bvh_optimise_mod, bvh_optimise_max_height, leaf_recut."""
         for k, v in kw.items():
             check(self._lib.pt_debug_set_tuning(self._h, self.TUNING_KEYS[k], int(v)))
 

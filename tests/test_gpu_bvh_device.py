@@ -275,3 +275,35 @@ def test_a_tree_the_passes_left_too_deep_is_put_back_as_built():
         _check_tree(nodes, prims, source)
         trees.append((nodes.tobytes(), prims.tobytes()))
     assert trees[0] == trees[1]
+
+
+@pytest.mark.parametrize("cut", [1, 2, 3])
+def test_uploaded_tree_with_its_leaves_cut_renders_the_same(cut):
+    """leaf_recut: the caller's tree traversed as uploaded, its leaves of up to four triangles cut into leaves of at most
+    `cut` under new interior nodes.  Same image as with the leaves as they are (up to exact distance ties), fewer triangle
+    tests per ray."""
+    from tests.common import built_scene
+    nodes, prims, mats = built_scene("BunnyGlass")
+    hdri, cache = environment(256, 128)
+    width, height = 160, 128
+    p = R.default_params(width, height)
+    p.max_bounces = 8
+    images, tests_per_ray = {}, {}
+    for setting in (0, cut):
+        g = R.Renderer(width, height)
+        g.set_bvh_rebuild(False)
+        g.set_tuning(leaf_recut=setting)
+        g.upload_nodes(nodes)
+        g.upload_primitives(prims)
+        g.upload_materials(mats)
+        g.upload_environment(hdri, cache)
+        g.set_params(p)
+        g.clear()
+        g.dispatch(1, 2, 1, counted=True)
+        st = g.stats()
+        tests_per_ray[setting] = st.triangle_tests / (st.rays_closest + st.rays_any)
+        images[setting] = [g.read_image(k) for k in range(3)]
+    for a, b in zip(images[0], images[cut]):
+        differing = int(np.any(a.view(np.uint32) != b.view(np.uint32), axis=-1).sum())
+        assert differing <= 1e-4 * width * height, differing
+    assert tests_per_ray[cut] < tests_per_ray[0], tests_per_ray

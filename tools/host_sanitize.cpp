@@ -130,6 +130,29 @@ static void exerciseBvh(const std::string& tmpDir)
                 std::exit(5);
             }
             if (count == 0) continue;
+            // the same tree with its leaves cut to two and to one triangle: every triangle still in exactly one leaf
+            for (int cut = 1; cut <= 2; cut++) {
+                PackedScene recut;
+                const std::string e2 = PackScene(nodes48.data(), nodes48.size(), prims112.data(), prims112.size(), 3, recut, cut);
+                if (!e2.empty()) std::exit(6);
+                std::vector<int> covered(prims112.size(), 0);
+                std::vector<int32_t> walk{recut.rootRef};
+                while (!walk.empty()) {
+                    const int32_t r = walk.back();
+                    walk.pop_back();
+                    if (r < 0) {
+                        const uint32_t bits = ~(uint32_t)r, first = bits >> 3, n2 = (bits & 7u) + 1u;
+                        if ((int)n2 > cut) std::exit(7);
+                        for (uint32_t t = first; t < first + n2; t++) covered[t]++;
+                    } else {
+                        if (r == 0 || (size_t)r >= recut.nodes.size()) std::exit(8);
+                        walk.push_back(recut.nodes[(size_t)r].left);
+                        walk.push_back(recut.nodes[(size_t)r].right);
+                    }
+                }
+                for (int cvr : covered)
+                    if (cvr != 1) std::exit(9);
+            }
             // a material table that is too short, and trees with damaged links, must be refused, not walked
             PackedScene rejected;
             (void)PackScene(nodes48.data(), nodes48.size(), prims112.data(), prims112.size(), 1, rejected);
