@@ -307,3 +307,15 @@ def test_uploaded_tree_with_its_leaves_cut_renders_the_same(cut):
         differing = int(np.any(a.view(np.uint32) != b.view(np.uint32), axis=-1).sum())
         assert differing <= 1e-4 * width * height, differing
     assert tests_per_ray[cut] < tests_per_ray[0], tests_per_ray
+
+
+def test_random_soups_and_builder_settings_give_valid_trees():
+    """A few seconds of tools/bvh_fuzz.py: random soups (spheres, clumps far apart, coincident triangles, needles, a plane
+    under one huge triangle) through the builder with random radius, passes, candidate spacing and leaf size."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "tools", "bvh_fuzz.py"), "6", "11"], capture_output=True, text=True,
+                         timeout=110, cwd=root)
+    assert run.returncode == 0 and "all trees valid" in run.stdout, run.stdout[-1500:] + run.stderr[-1500:]
