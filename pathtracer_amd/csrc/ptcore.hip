@@ -1884,7 +1884,7 @@ int buildPlocTopology(pt_ctx* c, LbvhScratch& w, const RefPrimitiveAlign* dIn, i
         int* rOld = (int*)((char*)w.boxB.ptr + count * 16);
         unsigned int* rVisits = (unsigned int*)w.nearest.ptr;
         unsigned int* rDirty = (unsigned int*)w.idA.ptr;
-        unsigned int* rPending = (unsigned int*)w.idB.ptr;  // (the refit's stamps)
+        unsigned int* rStamp = (unsigned int*)w.idB.ptr;  // (the refit's stamps)
         int* rLeft0 = (int*)w.keys.ptr;
         int* rRight0 = (int*)((char*)w.keys.ptr + count * 4);
         ReinsertTree R{rParent, N.left, N.right, N.box, n};
@@ -1919,17 +1919,17 @@ int buildPlocTopology(pt_ctx* c, LbvhScratch& w, const RefPrimitiveAlign* dIn, i
             hipLaunchKernelGGL(reinsertApplyKernel, grid(total), block, 0, st, R, (const int*)rOut, rOld, rMoves + pass);
             // boxes, counts and heights above the moves' old and new places (the rest of the tree has not changed)
             HIP_TRY(hipMemsetAsync(rDirty, 0, internal * 4, st));
-            HIP_TRY(hipMemsetAsync(rPending, 0, internal * 4, st));
+            HIP_TRY(hipMemsetAsync(rStamp, 0, internal * 4, st));
             hipLaunchKernelGGL(reinsertMarkKernel, grid(total), block, 0, st, R, (const int*)rOut, (const int*)rOld, rDirty);
             // one launch per level of flagged nodes; the root's stamp says when the refit is complete (the tree's height,
             // known from the pass before, is how many launches that takes unless the pass made the tree deeper)
             unsigned int round = 0, rootStamp = 0;
             for (;;) {
                 for (int k = 0; k < heightNow + 2; k++)
-                    hipLaunchKernelGGL(reinsertRefitMarkedKernel, grid(internal), block, 0, st, R, N, (const unsigned int*)rDirty, rPending, round++);
+                    hipLaunchKernelGGL(reinsertRefitMarkedKernel, grid(internal), block, 0, st, R, N, (const unsigned int*)rDirty, rStamp, round++);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(&moves[(size_t)pass], rMoves + pass, 4, hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipMemcpyAsync(&rootStamp, rPending + (n - 2), 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(&rootStamp, rStamp + (n - 2), 4, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipMemcpyAsync(&heightNow, N.height + (n - 2), 4, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
                 if (moves[(size_t)pass] == 0u || rootStamp != 0u) break;
